@@ -1,0 +1,130 @@
+"""Seeded synthetic CLIP weights under the OpenAI `state_dict` key names.
+
+There are no CLIP checkpoints offline, so parity and throughput
+are measured on random-init towers of the true dimensions.  Standard deviations
+follow the published openai/CLIP `initialize_parameters`; LayerNorm affine
+parameters and biases are perturbed away from (1, 0) so that a kernel which
+drops one of them cannot pass a parity test.  A user who has real weights loads
+them through `load_state_dict` with the same keys.
+"""
+import math
+
+import numpy as np
+
+from . import rng
+from .config import ClipDims
+
+
+def _block_keys(prefix, width):
+    w = width
+    return [
+        (f"{prefix}.ln_1.weight", (w,), "ln_w"),
+        (f"{prefix}.ln_1.bias", (w,), "ln_b"),
+        (f"{prefix}.attn.in_proj_weight", (3 * w, w), "attn"),
+        (f"{prefix}.attn.in_proj_bias", (3 * w,), "bias"),
+        (f"{prefix}.attn.out_proj.weight", (w, w), "proj"),
+        (f"{prefix}.attn.out_proj.bias", (w,), "bias"),
+        (f"{prefix}.ln_2.weight", (w,), "ln_w"),
+        (f"{prefix}.ln_2.bias", (w,), "ln_b"),
+        (f"{prefix}.mlp.c_fc.weight", (4 * w, w), "fc"),
+        (f"{prefix}.mlp.c_fc.bias", (4 * w,), "bias"),
+        (f"{prefix}.mlp.c_proj.weight", (w, 4 * w), "proj"),
+        (f"{prefix}.mlp.c_proj.bias", (w,), "bias"),
+    ]
+
+
+def weight_spec(d: ClipDims):
+    """Ordered [(key, shape, kind)] for the ViT + text CLIP the reference uses."""
+    vw, tw, p = d.vision_width, d.transformer_width, d.vision_patch_size
+    spec = [
+        ("visual.conv1.weight", (vw, 3, p, p), "conv"),
+        ("visual.class_embedding", (vw,), "vscale"),
+        ("visual.positional_embedding", (d.vision_seq, vw), "vscale"),
+        ("visual.ln_pre.weight", (vw,), "ln_w"),
+        ("visual.ln_pre.bias", (vw,), "ln_b"),
+    ]
+    for i in range(d.vision_layers):
+        spec += [(k, s, "v" + kind) for k, s, kind in _block_keys(f"visual.transformer.resblocks.{i}", vw)]
+    spec += [
+        ("visual.ln_post.weight", (vw,), "ln_w"),
+        ("visual.ln_post.bias", (vw,), "ln_b"),
+        ("visual.proj", (vw, d.embed_dim), "vscale"),
+        ("token_embedding.weight", (d.vocab_size, tw), "tok"),
+        ("positional_embedding", (d.context_length, tw), "pos"),
+    ]
+    for i in range(d.transformer_layers):
+        spec += [(k, s, "t" + kind) for k, s, kind in _block_keys(f"transformer.resblocks.{i}", tw)]
+    spec += [
+        ("ln_final.weight", (tw,), "ln_w"),
+        ("ln_final.bias", (tw,), "ln_b"),
+        ("text_projection", (tw, d.embed_dim), "tproj"),
+        ("logit_scale", (), "logit_scale"),
+    ]
+    return spec
+
+
+def _std(kind, d: ClipDims):
+    vw, tw = d.vision_width, d.transformer_width
+    if kind in ("vscale",):
+        return vw ** -0.5
+    if kind == "conv":
+        return (3 * d.vision_patch_size ** 2) ** -0.5
+    if kind == "tok":
+        return 0.02
+    if kind == "pos":
+        return 0.01
+    if kind == "tproj":
+        return tw ** -0.5
+    tower, k = kind[0], kind[1:]
+    w = vw if tower == "v" else tw
+    layers = d.vision_layers if tower == "v" else d.transformer_layers
+    if k == "attn":
+        return w ** -0.5
+    if k == "proj":
+        return (w ** -0.5) * ((2 * layers) ** -0.5)
+    if k == "fc":
+        return (2 * w) ** -0.5
+    raise KeyError(kind)
+
+
+def init_state_dict(d: ClipDims, seed: int = 0, logit_scale: float = math.log(100.0)):
+    """dict[key] -> float32 numpy array, deterministic in (dims, seed)."""
+    out = {}
+    for key, shape, kind in weight_spec(d):
+        sid = rng.stream_id(key)
+        base = kind[1:] if kind[0] in "vt" and kind[1:] in ("ln_w", "ln_b", "bias", "attn", "proj", "fc") else kind
+        if base == "ln_w":
+            a = rng.normal(seed, sid, shape, 1.0, 0.1)
+        elif base in ("ln_b", "bias"):
+            a = rng.normal(seed, sid, shape, 0.0, 0.05)
+        elif base == "logit_scale":
+            a = np.array(logit_scale, dtype=np.float32)
+        else:
+            a = rng.normal(seed, sid, shape, 0.0, _std(kind, d))
+        out[key] = a
+    return out
+
+
+def init_upt_mixer(coop_dim: int, vpt_dim: int, tdim: int = 128, seed: int = 0):
+    """Seeded parameters of UPTModel's prompt mixer (models/prompts_models.py:99-119):
+    four nn.Linear and a 1-layer, 1-head CLIP Transformer of width `tdim`."""
+    out = {}
+
+    def lin(name, o, i):
+        out[f"{name}.weight"] = rng.normal(seed, rng.stream_id("upt." + name + ".weight"), (o, i), 0.0, i ** -0.5)
+        out[f"{name}.bias"] = rng.normal(seed, rng.stream_id("upt." + name + ".bias"), (o,), 0.0, 0.05)
+
+    lin("proj_coop_pre", tdim, coop_dim)
+    lin("proj_coop_post", coop_dim, tdim)
+    lin("proj_vpt_pre", tdim, vpt_dim)
+    lin("proj_vpt_post", vpt_dim, tdim)
+    for key, shape, kind in _block_keys("transformer.resblocks.0", tdim):
+        sid = rng.stream_id("upt." + key)
+        if kind == "ln_w":
+            a = rng.normal(seed, sid, shape, 1.0, 0.1)
+        elif kind in ("ln_b", "bias"):
+            a = rng.normal(seed, sid, shape, 0.0, 0.05)
+        else:
+            a = rng.normal(seed, sid, shape, 0.0, {"attn": tdim ** -0.5, "proj": tdim ** -0.5 * 2 ** -0.5, "fc": (2 * tdim) ** -0.5}[kind])
+        out[key] = a
+    return out
