@@ -1,0 +1,163 @@
+/* grip_amd.h -- C ABI of the MI355X-native CLIP prompt-tuning + pseudolabel engine.
+ *
+ * The reference (BatsResearch/menghini-neurips23-code) is pure Python and has no FFI; its
+ * "operator API" for the hot path is a set of Python classes over the third-party `clip`
+ * package.  Each entry point below replaces the arithmetic behind one of them; the Python
+ * host layer in menghini-neurips23-code_amd/{clip,models,utils} keeps the reference's class
+ * and function signatures and binds these symbols with ctypes.
+ *
+ * Conventions: extern "C"; every function returns 0 on success and a non-zero grip_status
+ * otherwise (grip_last_error() gives the message); no C++ exception crosses the boundary; the
+ * caller owns every buffer; all device work is enqueued on the caller's hipStream_t (passed as
+ * void*); handles are not thread-safe (one per process / GPU); no hidden device allocation after
+ * grip_tower_create.  Device pointers are plain pointers into HBM (torch tensors' data_ptr()).
+ *
+ * Dtypes: GEMM operands f16 (MFMA v_mfma_f32_16x16x32_f16, f32 accumulate); residual stream,
+ * LayerNorm, softmax, head, embeddings and gradients f32.
+ */
+#ifndef GRIP_AMD_H
+#define GRIP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GRIP_OK = 0,
+    GRIP_ERR_ARG = 1,        /* bad dimension / null pointer / unsupported shape */
+    GRIP_ERR_HIP = 2,        /* a HIP runtime call or kernel launch failed */
+    GRIP_ERR_WORKSPACE = 3,  /* workspace too small */
+    GRIP_ERR_STATE = 4       /* backward without a matching training-mode forward, tower not finalized */
+} grip_status;
+
+const char* grip_last_error(void);
+/* ABI version of this header; the host layer refuses a library that reports another one. */
+int grip_abi_version(void);
+#define GRIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------
+ * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
+ * CustomVisionTransformer, models/clip_encoders.py:105-194), kind 1 = text transformer
+ * (clip_model.{token_embedding, positional_embedding, transformer, ln_final, text_projection},
+ * wrapped by CustomTextEncoder, models/clip_encoders.py:25-90).  Head dim is width / heads = 64. */
+typedef struct {
+    int32_t kind;        /* 0 vision, 1 text */
+    int32_t width;       /* d: 768 (ViT-B), 1024 (ViT-L); text 512 / 768 */
+    int32_t layers;
+    int32_t heads;       /* width / 64 */
+    int32_t embed_dim;   /* E: 512 / 768 */
+    int32_t seq0;        /* tokens without prompt: grid^2 + 1 (vision) or context length 77 (text) */
+    int32_t patch;       /* vision: patch size; text: 0 */
+    int32_t resolution;  /* vision: input resolution; text: 0 */
+    int32_t vocab;       /* text: vocabulary size; vision: 0 */
+    int32_t max_prefix;  /* largest number of prompt tokens any call will use (sizes nothing but checks) */
+} grip_dims;
+
+/* Weight layout.  A tower's frozen weights live in two caller-owned device blobs: one f16 (GEMM
+ * operands) and one f32 (biases, LayerNorm affine, embeddings).  grip_layout_slot enumerates the
+ * slots: `name` is the OpenAI state_dict key relative to the tower (e.g.
+ * "transformer.resblocks.3.attn.in_proj_weight", "conv1.weight", "proj") for primary slots the
+ * host fills, or ends in "#T" for derived slots (transposed copies used by the backward pass,
+ * written by grip_tower_finalize).  Returns GRIP_OK, or GRIP_ERR_ARG when `slot` is past the end. */
+typedef struct {
+    char name[96];
+    int32_t dtype;      /* 0 = f16 blob, 1 = f32 blob */
+    int32_t derived;    /* 1 = written by grip_tower_finalize */
+    int64_t offset;     /* element offset inside its blob (16-byte aligned) */
+    int64_t rows;       /* logical shape rows x cols, row-major */
+    int64_t cols;
+    int64_t ld;         /* leading dimension in elements (>= cols; conv1 rows are zero-padded to a multiple of 64) */
+} grip_slot;
+
+int grip_layout_slot(const grip_dims* dims, int slot, grip_slot* out);
+int grip_layout_size(const grip_dims* dims, int64_t* n_f16, int64_t* n_f32);
+
+typedef struct grip_tower grip_tower;
+
+/* Replaces clip.load's module construction for one tower.  Blobs must outlive the handle. */
+int grip_tower_create(const grip_dims* dims, void* f16_blob, void* f32_blob, grip_tower** out);
+/* Builds derived weights (transposed copies) on `stream`; call after the primary slots are filled
+ * and again whenever they change. */
+int grip_tower_finalize(grip_tower* t, void* stream);
+int grip_tower_destroy(grip_tower* t);
+
+/* Workspace bytes for a forward over `batch` units (images, or class prompts for the text tower)
+ * with `n_prefix` prompt tokens.  train != 0 keeps the activations backward needs. */
+int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int train, size_t* bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * CustomVisionTransformer.forward(x, image_prefix) / clip_model.encode_image(x)
+ * (models/clip_encoders.py:123-194; :93-102 with n_prefix = 0).
+ *   images     [batch, 3, R, R] f32 (images_f16 = 0) or f16 (images_f16 = 1), NCHW
+ *   prefix     [n_prefix, width] f32, or NULL when n_prefix == 0; inserted between CLS and the
+ *              patches after the positional embedding, shared by the whole batch
+ *   out_emb    [batch, embed_dim] f32 (un-normalised, as the reference returns it)
+ */
+int grip_vit_forward(grip_tower* t, const void* images, int images_f16, const float* prefix, int n_prefix,
+                     int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, void* stream);
+
+/* Input-gradient chain of the frozen ViT down to the prompt slice (autograd of the above w.r.t.
+ * image_prefix only; no weight gradients exist).  Must follow a train-mode forward on the same
+ * workspace.  grad_emb [batch, embed_dim] f32 -> grad_prefix [n_prefix, width] f32 (summed over batch). */
+int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* prefix, float* grad_prefix,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* CustomTextEncoder.forward(class_embeddings, classes) / clip_model.encode_text(tokens)
+ * (models/clip_encoders.py:43-90; :13-22 with n_prefix = 0).  Tokenisation stays on the host.
+ *   token_ids  [n_class, seq0] int32 device; eot_index [n_class] int32 device (= token_ids.argmax(-1))
+ *   prefix     [prefix_classes, n_prefix, width] f32; prefix_classes is 1 (broadcast, CoOp) or n_class
+ *   out_emb    [n_class, embed_dim] f32
+ */
+int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
+                      int n_prefix, int prefix_classes, int n_class, float* out_emb,
+                      void* workspace, size_t workspace_bytes, int train, void* stream);
+
+/* grad_emb [n_class, embed_dim] -> grad_prefix [prefix_classes, n_prefix, width] (summed over classes
+ * when prefix_classes == 1). */
+int grip_text_backward_prefix(grip_tower* t, const float* grad_emb, float* grad_prefix,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cosine x logit-scale head + softmax + argmax: the block inlined 45 times in the reference, e.g.
+ * methods/semi_supervised_learning/textual_prompt.py:98-109, and utils/clip_pseudolabels.py:35-41.
+ *   img_emb [n, e] f32, txt_emb [c, e] f32 (both un-normalised), scale = logit_scale.exp()
+ *   logits [n, c] f32; probs [n, c] f32 (softmax) or NULL; argmax_logits / argmax_probs [n] int32 or NULL
+ *   txt_norm_scratch [c, e] f32 device scratch
+ */
+int grip_cosine_head(const float* img_emb, const float* txt_emb, float scale, int n, int c, int e,
+                     float* logits, float* probs, int32_t* argmax_logits, int32_t* argmax_probs,
+                     float* txt_norm_scratch, void* stream);
+
+/* Backward of logits = scale * normalize(img) @ normalize(txt).T :
+ * grad_logits [n, c] -> grad_img [n, e] and/or grad_txt [c, e] (either may be NULL). */
+int grip_cosine_head_backward(const float* img_emb, const float* txt_emb, float scale, int n, int c, int e,
+                              const float* grad_logits, float* grad_img, float* grad_txt, void* stream);
+
+/* Mean cross-entropy over the rows with row_weight != 0, each weighted: the three FPL losses
+ * (methods/semi_supervised_learning/textual_fpl.py:123-165, methods/transductive_zsl/textual_fpl.py:117-147,
+ * methods/unsupervised_learning/visual_fpl.py:107-122) are sums of two such masked means; the host
+ * passes per-row weights w_i = gamma_group / |group|.  loss [1] f32, grad_logits [n, c] f32. */
+int grip_weighted_ce(const float* logits, const int32_t* labels, const float* row_weight, int n, int c,
+                     float* loss, float* grad_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sequential per-class leaderboard: utils/clip_pseudolabels.py:49-112 and the nine
+ * assign_pseudo_labels (e.g. methods/transductive_zsl/multimodal_fpl.py:194-285).  Host function,
+ * exact: order-dependent, one pass in dataset order.
+ *   probs [n, c] f32 host; pred [n] int32 host (arg-max the caller took: of probs in
+ *   clip_pseudolabels.py:39, of logits in assign_pseudo_labels)
+ *   path_rank [n] int64 host: rank of image i's path string among all paths (ties in the score are
+ *   broken by the path, descending; equal strings get equal ranks)
+ *   out_img / out_class: capacity c * min(k, n); *out_count = pairs emitted, boards concatenated
+ *   in class order, each in its final list order.
+ */
+int grip_leaderboard_scan(const float* probs, const int32_t* pred, const int64_t* path_rank,
+                          int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIP_AMD_H */

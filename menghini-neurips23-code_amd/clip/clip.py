@@ -1,0 +1,78 @@
+"""`clip.load` / `clip.tokenize` of the native engine (same call signatures as openai-CLIP's)."""
+import hashlib
+import os
+import re
+
+import torch
+
+from .. import config as _cfg, weights as _weights
+from . import model  # noqa: F401
+from .model import CLIP
+
+_WORD = re.compile(r"[a-z]+|[0-9]|[^\sa-z0-9]+")
+
+
+def _word_id(w: str) -> int:
+    if w == "x":
+        return _cfg.X_TOKEN
+    h = int.from_bytes(hashlib.sha256(w.encode()).digest()[:4], "little")
+    return 1000 + h % 39000
+
+
+def tokenize(texts, context_length: int = 77, truncate: bool = False):
+    """[n, 77] int tensor [SOT, ids..., EOT, 0...].  STAND-IN word-hash tokenizer: the BPE
+    vocabulary file is not available offline; structure (SOT/EOT, "X" -> 343,
+    EOT = largest id) is what CustomTextEncoder relies on (models/clip_encoders.py:54-60,86-89)."""
+    if isinstance(texts, str):
+        texts = [texts]
+    out = torch.zeros(len(texts), context_length, dtype=torch.int)
+    for i, t in enumerate(texts):
+        ids = [_cfg.SOT_TOKEN] + [_word_id(w) for w in _WORD.findall(t.lower())] + [_cfg.EOT_TOKEN]
+        if len(ids) > context_length:
+            if not truncate:
+                raise RuntimeError(f"Input {t} is too long for context length {context_length}")
+            ids = ids[:context_length]
+            ids[-1] = _cfg.EOT_TOKEN
+        out[i, : len(ids)] = torch.tensor(ids, dtype=torch.int)
+    return out
+
+
+def available_models():
+    return [k for k in _cfg.CLIP_CONFIGS]
+
+
+def _preprocess(n_px):
+    def transform(img):
+        """CLIP preprocessing is a NEXT row; tensors pass through unchanged."""
+        if torch.is_tensor(img):
+            return img
+        raise NotImplementedError("PIL preprocessing is not part of the round-1 hot path; pass [3,R,R] tensors")
+    transform.n_px = n_px
+    return transform
+
+
+def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0):
+    """(model, preprocess).  Weights: $CLIP_WEIGHTS (a torch-saved OpenAI state_dict) when set,
+    else the seeded synthetic init of grip_amd.weights (no checkpoints exist offline)."""
+    d = _cfg.get_dims(name)
+    m = CLIP(d, device)
+    path = os.environ.get("CLIP_WEIGHTS")
+    if path:
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+    else:
+        sd = {k: torch.from_numpy(v) for k, v in _weights.init_state_dict(d, seed).items()}
+    load_openai_state_dict(m, sd)
+    return m, _preprocess(d.image_resolution)
+
+
+def load_openai_state_dict(m: CLIP, sd):
+    own = dict(m.named_parameters())
+    missing = [k for k in own if k not in sd]
+    if missing:
+        raise RuntimeError(f"state_dict is missing keys: {missing[:5]}...")
+    with torch.no_grad():
+        for k, p in own.items():
+            p.copy_(sd[k].reshape(p.shape).to(p.dtype))
+    m.visual.tower.finalize()
+    m.tower.finalize()

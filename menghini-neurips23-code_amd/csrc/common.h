@@ -1,0 +1,79 @@
+// Shared device/host helpers for the gfx950 kernels (wave = 64 lanes, MFMA 16x16x32 f16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/grip_amd.h"
+
+typedef _Float16 half_t;
+typedef half_t half8 __attribute__((ext_vector_type(8)));
+typedef half_t half4 __attribute__((ext_vector_type(4)));
+typedef half_t half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+void grip_set_error(const char* fmt, ...);
+
+#define GRIP_CHECK_HIP(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            grip_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return GRIP_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+#define GRIP_REQUIRE(cond, ...)             \
+    do {                                    \
+        if (!(cond)) {                      \
+            grip_set_error(__VA_ARGS__);    \
+            return GRIP_ERR_ARG;            \
+        }                                   \
+    } while (0)
+
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------------
+// GEMM: C[M,N] = epilogue(A[M,K] * W[N,K]^T).  A and W are f16, K-contiguous; accumulate f32.
+enum GemmEpi {
+    EPI_F32 = 0,             // out_f32 = acc
+    EPI_BIAS_F16 = 1,        // out_f16 = acc + bias
+    EPI_BIAS_GELU_F16 = 2,   // out_f16 = quickgelu(acc + bias); if out2 != null, out2_f16 = acc + bias (pre-activation)
+    EPI_BIAS_RESID_F32 = 3,  // out_f32 = resid + acc + bias
+    EPI_F16 = 4,             // out_f16 = acc
+    EPI_GELUGRAD_F16 = 5,    // out_f16 = acc * quickgelu'(aux_f16)       (backward of c_fc activation)
+    EPI_F32_SCALE = 6,       // out_f32 = acc * scalar
+};
+
+struct GemmArgs {
+    const half_t* A;    // [Mpad, K], lda = K; rows >= M may hold anything finite or not (never stored)
+    const half_t* W;    // [N, K]
+    int M, N, K;
+    const float* bias;  // [N] or null
+    const float* resid; // [M, ldc] f32 (EPI_BIAS_RESID_F32)
+    const half_t* aux;  // [M, ldc] f16 (EPI_GELUGRAD_F16)
+    void* out;          // [M, ldc] f16 or f32
+    void* out2;         // optional second output
+    int ldc;
+    float scalar;
+};
+
+int launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
+
+// row-wise kernels (rowops.hip)
+int launch_im2col(const void* images, int images_f16, half_t* out, int B, int R, int patch, int Kpad, hipStream_t s);
+int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
+                           const float* gamma, const float* beta, float* x, int B, int G2, int d, hipStream_t s);
+int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
+int launch_gather_ln_f16(const float* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
+                         half_t* out, int n_rows, int d, hipStream_t s);
+int launch_text_embed(const int32_t* token_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
+                      int prefix_classes, float* x, int C, int T, int d, int vocab, hipStream_t s);
+int launch_transpose_f16(const half_t* in, half_t* out, int rows, int cols, int ld_in, hipStream_t s);
+
+// attention (attention.hip): qkv [B*S, 3*D] f16 -> out [B*S, D] f16
+int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s);

@@ -1,0 +1,170 @@
+// f16 MFMA GEMM for gfx950: C[M,N] = epi(A[M,K] * W[N,K]^T), f32 accumulate.
+//
+// Block tile 128x128x64, 256 threads = 4 waves in a 2x2 grid, each wave a 64x64 sub-tile of
+// 4x4 v_mfma_f32_16x16x32_f16 fragments.  A and W tiles go HBM -> LDS with direct
+// global_load_lds (16 B per lane, 1 KiB per wave instruction, lane-linear LDS image); the 16-byte
+// chunk index is XOR-swizzled with (row & 7) on the SOURCE address and again on the ds_read_b128
+// address, which makes the fragment reads bank-conflict free (guide T2 / rule 21).  Two LDS
+// stages: the loads of tile t+1 are issued right after the barrier that publishes tile t and fly
+// under its 32 MFMAs per wave; one barrier per K tile.
+// The MFMA is issued with swapped operands (W fragment first) so each lane ends up with four
+// CONSECUTIVE output columns of one row: the epilogue reads bias / residual and writes C with
+// 8-byte (f16) or 16-byte (f32) accesses.
+// Workgroup ids are remapped so every XCD (private 4 MiB L2) owns a contiguous run of tiles,
+// N-fastest: the A row panel and the W panel stay L2-resident across the run.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define STAGE_HALFS ((BM + BN) * BK)  // 16384 halfs = 32 KiB
+
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * STAGE_HALFS];
+
+    // ---- XCD-aware, bijective tile remap (block b runs on XCD b % 8)
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- staging addresses: wave w fills rows [w*32, w*32+32) of the A tile and of the W tile,
+    // 8 rows (1 KiB) per instruction; lane l -> row l>>3, LDS chunk l&7, source chunk (l&7)^(l>>3).
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const size_t K = (size_t)g.K;
+    const half_t* a_src = g.A + (size_t)(m0 + wave * 32 + srow) * K + schunk * 8;
+    const half_t* w_src = g.W + (size_t)(n0 + wave * 32 + srow) * K + schunk * 8;
+
+    auto stage = [&](int buf, int kt) {
+        half_t* base = lds + buf * STAGE_HALFS + wave * 32 * BK;
+        const half_t* as = a_src + (size_t)kt * BK;
+        const half_t* ws = w_src + (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 8 * K), (AS3 void*)(base + i * 8 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 8 * K), (AS3 void*)(base + BM * BK + i * 8 * BK), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (in halfs) inside a stage
+    const int frow = lane & 15;        // row inside a 16-row fragment; (row & 7) == (lane & 7)
+    const int fgrp = lane >> 4;        // k-chunk group 0..3
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
+        a_off[kk] = (wr * 64 + frow) * BK + chunk * 8;
+        b_off[kk] = BM * BK + (wc * 64 + frow) * BK + chunk * 8;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        __syncthreads();  // waits vmcnt(0) for this wave's LDS-DMA, then barrier: tile kt visible, tile kt-1 fully read
+        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        const half_t* st = lds + buf * STAGE_HALFS;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds C[row = m0 + wr*64 + i*16 + (lane&15)][col = n0 + wc*64 + j*16 + (lane>>4)*4 + 0..3]
+    const int ldc = g.ldc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wr * 64 + i * 16 + frow;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wc * 64 + j * 16 + fgrp * 4;
+            f32x4 v = acc[i][j];
+            const size_t o = (size_t)row * ldc + col;
+            if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID_F32) {
+                const f32x4 b = *(const f32x4*)(g.bias + col);
+                v += b;
+            }
+            if constexpr (EPI == EPI_F32) {
+                *(f32x4*)((float*)g.out + o) = v;
+            } else if constexpr (EPI == EPI_F32_SCALE) {
+                *(f32x4*)((float*)g.out + o) = v * g.scalar;
+            } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                const f32x4 r = *(const f32x4*)(g.resid + o);
+                *(f32x4*)((float*)g.out + o) = v + r;
+            } else if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_F16) {
+                half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *(half4*)((half_t*)g.out + o) = h;
+            } else if constexpr (EPI == EPI_BIAS_GELU_F16) {
+                if (g.out2) {
+                    half4 p = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *(half4*)((half_t*)g.out2 + o) = p;
+                }
+                half4 h = {(half_t)quick_gelu(v[0]), (half_t)quick_gelu(v[1]), (half_t)quick_gelu(v[2]), (half_t)quick_gelu(v[3])};
+                *(half4*)((half_t*)g.out + o) = h;
+            } else if constexpr (EPI == EPI_GELUGRAD_F16) {
+                const half4 x = *(const half4*)(g.aux + o);
+                half4 h = {(half_t)(v[0] * quick_gelu_grad((float)x[0])), (half_t)(v[1] * quick_gelu_grad((float)x[1])),
+                           (half_t)(v[2] * quick_gelu_grad((float)x[2])), (half_t)(v[3] * quick_gelu_grad((float)x[3]))};
+                *(half4*)((half_t*)g.out + o) = h;
+            }
+        }
+    }
+}
+
+int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
+    GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+#define GRIP_GEMM_CASE(E) \
+    case E: hipLaunchKernelGGL(gemm_f16_kernel<E>, grid, block, 0, s, a, tiles_m, tiles_n); break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_F32)
+        GRIP_GEMM_CASE(EPI_F16)
+        GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
+        GRIP_GEMM_CASE(EPI_F32_SCALE)
+        default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

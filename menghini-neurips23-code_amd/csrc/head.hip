@@ -1,0 +1,122 @@
+// Cosine x logit-scale head with fused softmax / arg-max (all f32): the block the reference inlines
+// 45 times (e.g. methods/semi_supervised_learning/textual_prompt.py:98-109) and the tail of
+// clip_model(image, text) + softmax + argmax in utils/clip_pseudolabels.py:35-41.
+// HBM-bound: n*e*4 bytes in, n*c*8 bytes out; the c*e text matrix is L2-resident.
+// One wave per image row: the row is normalised and pre-multiplied by the scale in registers
+// (the reference computes (scale * img_n) @ txt_n.T), then each class is one 64-lane dot product.
+#include <math.h>
+
+#include "common.h"
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// out[r] = in[r] / ||in[r]||
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int e) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* x = in + (size_t)row * e;
+    float q = 0.f;
+    for (int i = lane; i < e; i += 64) q += x[i] * x[i];
+    const float nrm = sqrtf(wsum(q));
+    for (int i = lane; i < e; i += 64) out[(size_t)row * e + i] = x[i] / nrm;
+}
+
+#define HEAD_MAX_EV 8  // e <= 64 * 4 * 8 = 2048
+#define HEAD_MAX_CV 16 // c <= 1024
+
+__global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restrict__ img, const float* __restrict__ txtn, float scale,
+                                                          int n, int c, int e, float* __restrict__ logits, float* __restrict__ probs,
+                                                          int32_t* __restrict__ am_logits, int32_t* __restrict__ am_probs) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int e4 = e >> 2;
+    const f32x4* x = (const f32x4*)(img + (size_t)row * e);
+    f32x4 v[HEAD_MAX_EV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEAD_MAX_EV; ++i)
+        if (lane + 64 * i < e4) {
+            v[i] = x[lane + 64 * i];
+            q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    const float nrm = sqrtf(wsum(q));
+#pragma unroll
+    for (int i = 0; i < HEAD_MAX_EV; ++i)
+        if (lane + 64 * i < e4) v[i] = scale * (v[i] / nrm);
+
+    float lg[HEAD_MAX_CV];  // lane l keeps classes l, l+64, ...
+    for (int j = 0; j < c; ++j) {
+        const f32x4* t = (const f32x4*)(txtn + (size_t)j * e);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < HEAD_MAX_EV; ++i)
+            if (lane + 64 * i < e4) {
+                const f32x4 w = t[lane + 64 * i];
+                d += v[i][0] * w[0] + v[i][1] * w[1] + v[i][2] * w[2] + v[i][3] * w[3];
+            }
+        d = wsum(d);
+#pragma unroll
+        for (int s = 0; s < HEAD_MAX_CV; ++s)
+            if ((j >> 6) == s && (j & 63) == lane) lg[s] = d;
+    }
+    // row max + first arg-max over logits
+    float m = -INFINITY;
+    int am = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < HEAD_MAX_CV; ++s) {
+        const int j = s * 64 + lane;
+        if (j < c) {
+            logits[(size_t)row * c + j] = lg[s];
+            if (lg[s] > m) { m = lg[s]; am = j; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o);
+        const int oa = __shfl_xor(am, o);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    if (lane == 0 && am_logits) am_logits[row] = am;
+    if (!probs && !am_probs) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < HEAD_MAX_CV; ++s)
+        if (s * 64 + lane < c) { lg[s] = expf(lg[s] - m); sum += lg[s]; }
+    sum = wsum(sum);
+    float pm = -1.f;
+    int pa = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < HEAD_MAX_CV; ++s) {
+        const int j = s * 64 + lane;
+        if (j < c) {
+            const float p = lg[s] / sum;
+            if (probs) probs[(size_t)row * c + j] = p;
+            if (p > pm) { pm = p; pa = j; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(pm, o);
+        const int oa = __shfl_xor(pa, o);
+        if (om > pm || (om == pm && oa < pa)) { pm = om; pa = oa; }
+    }
+    if (lane == 0 && am_probs) am_probs[row] = pa;
+}
+
+extern "C" int grip_cosine_head(const float* img_emb, const float* txt_emb, float scale, int n, int c, int e,
+                                float* logits, float* probs, int32_t* argmax_logits, int32_t* argmax_probs,
+                                float* txt_norm_scratch, void* stream) {
+    GRIP_REQUIRE(img_emb && txt_emb && logits && txt_norm_scratch, "cosine_head: null pointer");
+    GRIP_REQUIRE(n > 0 && c > 0 && c <= 64 * HEAD_MAX_CV && e % 4 == 0 && e <= 256 * HEAD_MAX_EV, "cosine_head: unsupported shape n=%d c=%d e=%d", n, c, e);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((c + 3) / 4), dim3(256), 0, s, txt_emb, txt_norm_scratch, c, e);
+    hipLaunchKernelGGL(cosine_head_kernel, dim3((n + 3) / 4), dim3(256), 0, s, img_emb, txt_norm_scratch, scale, n, c, e, logits, probs, argmax_logits, argmax_probs);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

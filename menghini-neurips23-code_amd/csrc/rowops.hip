@@ -1,0 +1,243 @@
+// Row-wise, HBM-bound kernels of the CLIP towers: patch gather (im2col), sequence assembly with
+// prompt insertion + LayerNorm, LayerNorm f32 -> f16, CLS/EOT gather + LayerNorm, token-embedding
+// gather with prompt splice, f16 transpose.  One wave (64 lanes) owns one row of width d and keeps
+// it in registers as float4 chunks (lane l holds float4 index l + 64*i): every global access is a
+// 16-byte, fully coalesced access, statistics are two in-register passes + a 6-step xor reduction.
+#include "common.h"
+
+#define LN_EPS 1e-5f
+#define MAX_NV 8  // d <= 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void ln_normalize(f32x4 (&v)[NV], int lane, int d4, int d, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            f32x4 c = v[i] - mean;
+            q += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+        }
+    rstd = rsqrtf(wave_sum(q) / (float)d + LN_EPS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over rows of x (f32) -> f16.  row_index == null: row r reads x[r]; else row r reads
+// x[r * row_stride + row_index[r]] (EOT gather); row_stride alone gathers x[r * row_stride] (CLS).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_f16_kernel(const float* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     half_t* __restrict__ out, int n_rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int d4 = d >> 2;
+    size_t src = (size_t)row * row_stride + (row_index ? row_index[row] : 0);
+    const f32x4* xr = (const f32x4*)(x + src * d);
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) v[i] = xr[lane + 64 * i];
+    float mean, rstd;
+    ln_normalize<NV>(v, lane, d4, d, mean, rstd);
+    half4* o = (half4*)(out + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], b = ((const f32x4*)beta)[lane + 64 * i];
+            const f32x4 y = (v[i] - mean) * rstd * g + b;
+            o[lane + 64 * i] = (half4){(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+        }
+}
+
+#define DISPATCH_NV(d, CALL)                                                                   \
+    do {                                                                                       \
+        const int _nv = ((d) / 4 + 63) / 64;                                                   \
+        GRIP_REQUIRE((d) % 4 == 0 && _nv >= 1 && _nv <= MAX_NV, "row kernel: unsupported width %d", (d)); \
+        switch (_nv) {                                                                         \
+            case 1: { constexpr int NV = 1; CALL; } break;                                     \
+            case 2: { constexpr int NV = 2; CALL; } break;                                     \
+            case 3: { constexpr int NV = 3; CALL; } break;                                     \
+            case 4: { constexpr int NV = 4; CALL; } break;                                     \
+            case 5: case 6: { constexpr int NV = 6; CALL; } break;                             \
+            default: { constexpr int NV = 8; CALL; } break;                                    \
+        }                                                                                      \
+    } while (0)
+
+int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s) {
+    DISPATCH_NV(d, hipLaunchKernelGGL(ln_f16_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, (const int32_t*)nullptr, 1, gamma, beta, out, M, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+int launch_gather_ln_f16(const float* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
+                         half_t* out, int n_rows, int d, hipStream_t s) {
+    DISPATCH_NV(d, hipLaunchKernelGGL(ln_f16_kernel<NV>, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, row_index, row_stride, gamma, beta, out, n_rows, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vision sequence assembly + ln_pre  (models/clip_encoders.py:135-163):
+//   row (b, 0)            = class_embedding + pos[0]
+//   row (b, 1..P)         = prefix[s-1]                         (no positional embedding)
+//   row (b, 1+P+j)        = patch_out[b*G2 + j] + pos[1+j]
+// then LayerNorm -> x (f32 residual stream), S = 1 + P + G2.
+template <int NV>
+__global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, const float* __restrict__ prefix, int P,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ x, int B, int G2, int d) {
+    const int lane = threadIdx.x & 63;
+    const int S = 1 + P + G2;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * S) return;
+    const int b = row / S, s = row - b * S;
+    const int d4 = d >> 2;
+    f32x4 v[NV];
+    const f32x4* src;
+    const f32x4* add = nullptr;
+    if (s == 0) { src = (const f32x4*)cls; add = (const f32x4*)pos; }
+    else if (s <= P) { src = (const f32x4*)(prefix + (size_t)(s - 1) * d); }
+    else { const int j = s - 1 - P; src = (const f32x4*)(patch_out + ((size_t)b * G2 + j) * d); add = (const f32x4*)(pos + (size_t)(1 + j) * d); }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            v[i] = src[lane + 64 * i];
+            if (add) v[i] += add[lane + 64 * i];
+        }
+    float mean, rstd;
+    ln_normalize<NV>(v, lane, d4, d, mean, rstd);
+    f32x4* o = (f32x4*)(x + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], bb = ((const f32x4*)beta)[lane + 64 * i];
+            o[lane + 64 * i] = (v[i] - mean) * rstd * g + bb;
+        }
+}
+
+int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
+                           const float* gamma, const float* beta, float* x, int B, int G2, int d, hipStream_t s) {
+    const int rows = B * (1 + P + G2);
+    DISPATCH_NV(d, hipLaunchKernelGGL(vit_assemble_ln_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, x, B, G2, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Text embedding (models/clip_encoders.py:63-74): x[c, t] = (1 <= t <= P ? prefix[c or 0, t-1] : tok_emb[ids[c, t]]) + pos[t]
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos, const float* __restrict__ prefix, int P,
+                                                         int prefix_classes, float* __restrict__ x, int C, int T, int d, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= C * T) return;
+    const int c = row / T, t = row - c * T;
+    const int d4 = d >> 2;
+    const f32x4* src;
+    if (t >= 1 && t <= P) {
+        src = (const f32x4*)(prefix + ((size_t)(prefix_classes == 1 ? 0 : c) * P + (t - 1)) * d);
+    } else {
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        src = (const f32x4*)(tok_emb + (size_t)id * d);
+    }
+    const f32x4* pp = (const f32x4*)(pos + (size_t)t * d);
+    f32x4* o = (f32x4*)(x + (size_t)row * d);
+    for (int f = lane; f < d4; f += 64) o[f] = src[f] + pp[f];
+}
+
+int launch_text_embed(const int32_t* token_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
+                      int prefix_classes, float* x, int C, int T, int d, int vocab, hipStream_t s) {
+    GRIP_REQUIRE(d % 4 == 0, "text_embed: width %% 4 != 0");
+    hipLaunchKernelGGL(text_embed_kernel, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, tok_emb, pos, prefix, P, prefix_classes, x, C, T, d, vocab);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Patch gather (the conv1 of models/clip_encoders.py:131 as a GEMM operand):
+//   out[(b*G + py)*G + px][c*p*p + kh*p + kw] = img[b][c][py*p + kh][px*p + kw], zero-padded to Kpad.
+// One thread writes 8 consecutive k (16 bytes).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ img, half_t* __restrict__ out, int B, int R, int p, int Kpad) {
+    const int G = R / p;
+    const int K = 3 * p * p;
+    const int chunks = Kpad >> 3;
+    const size_t total = (size_t)B * G * G * chunks;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int chunk = (int)(idx % chunks);
+        const size_t prow = idx / chunks;
+        const int px = (int)(prow % G);
+        const int py = (int)((prow / G) % G);
+        const int b = (int)(prow / ((size_t)G * G));
+        const int k0 = chunk * 8;
+        half8 h;
+        if ((p & 7) == 0 && k0 + 8 <= K) {
+            const int c = k0 / (p * p), rem = k0 - c * p * p, kh = rem / p, kw = rem - kh * p;
+            const T* src = img + (((size_t)b * 3 + c) * R + (py * p + kh)) * R + px * p + kw;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)src[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                float v = 0.f;
+                if (k < K) {
+                    const int c = k / (p * p), rem = k - c * p * p, kh = rem / p, kw = rem - kh * p;
+                    v = (float)img[(((size_t)b * 3 + c) * R + (py * p + kh)) * R + px * p + kw];
+                }
+                h[j] = (half_t)v;
+            }
+        }
+        *(half8*)(out + prow * Kpad + k0) = h;
+    }
+}
+
+int launch_im2col(const void* images, int images_f16, half_t* out, int B, int R, int patch, int Kpad, hipStream_t s) {
+    GRIP_REQUIRE(R % patch == 0 && Kpad % 8 == 0, "im2col: bad geometry R=%d patch=%d", R, patch);
+    const int G = R / patch;
+    const size_t total = (size_t)B * G * G * (Kpad / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (images_f16)
+        hipLaunchKernelGGL(im2col_kernel<half_t>, dim3(blocks), dim3(256), 0, s, (const half_t*)images, out, B, R, patch, Kpad);
+    else
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)images, out, B, R, patch, Kpad);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[c][r] = in[r][c] (f16), 64x64 tiles through LDS; used once per weight in grip_tower_finalize.
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int rows, int cols, int ld_in) {
+    __shared__ half_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (half_t)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][i];
+    }
+}
+
+int launch_transpose_f16(const half_t* in, half_t* out, int rows, int cols, int ld_in, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_f16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, in, out, rows, cols, ld_in);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

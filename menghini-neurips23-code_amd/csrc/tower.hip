@@ -1,0 +1,396 @@
+// Tower handle, weight layout and the forward/backward launch sequences behind the C ABI
+// (include/grip_amd.h).  A tower is the frozen CLIP ViT (kind 0) or text transformer (kind 1);
+// the launch sequence follows CustomVisionTransformer.forward (models/clip_encoders.py:123-194)
+// and CustomTextEncoder.forward (:43-90) of the reference, with the per-block arithmetic of the
+// published openai/CLIP ResidualAttentionBlock: x += out_proj(MHSA(ln_1 x)); x += c_proj(QuickGELU(c_fc(ln_2 x))).
+//
+// HBM layout: residual stream x f32 [B*S, d] row-major (token-major, so every GEMM sees one
+// [M, K] x [N, K]^T problem over all images of the chunk); GEMM operands (LayerNorm output, packed
+// qkv [M, 3d], attention output, MLP hidden [M, 4d]) f16.  Row counts are padded to the 128-row GEMM
+// tile in the workspace; padding rows are never stored to and never read back.
+#include <stdarg.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+void grip_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* grip_last_error(void) { return g_err; }
+extern "C" int grip_abi_version(void) { return GRIP_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------- layout
+struct LayerW {
+    // f16 (element offsets into the f16 blob)
+    int64_t in_w, out_w, fc_w, proj_w;          // [3d,d] [d,d] [4d,d] [d,4d]
+    int64_t in_wT, out_wT, fc_wT, proj_wT;      // derived transposes: [d,3d] [d,d] [d,4d] [4d,d]
+    // f32
+    int64_t ln1_g, ln1_b, in_b, out_b, ln2_g, ln2_b, fc_b, proj_b;
+};
+struct Layout {
+    std::vector<grip_slot> slots;
+    std::vector<LayerW> layer;
+    int64_t n16 = 0, n32 = 0;
+    int kpad = 0;
+    // vision
+    int64_t conv_w = -1, cls = -1, pos = -1, lnpre_g = -1, lnpre_b = -1, lnpost_g = -1, lnpost_b = -1, proj = -1, projT = -1;
+    // text
+    int64_t tok = -1;
+};
+
+static int64_t add_slot(Layout& L, const std::string& name, int dtype, int derived, int64_t rows, int64_t cols, int64_t ld = 0) {
+    grip_slot s;
+    memset(&s, 0, sizeof(s));
+    snprintf(s.name, sizeof(s.name), "%s", name.c_str());
+    s.dtype = dtype;
+    s.derived = derived;
+    s.rows = rows;
+    s.cols = cols;
+    s.ld = ld ? ld : cols;
+    int64_t& n = dtype == 0 ? L.n16 : L.n32;
+    n = round_up64(n, 64);  // 128-byte (f16) / 256-byte (f32) aligned slots
+    s.offset = n;
+    n += rows * s.ld;
+    L.slots.push_back(s);
+    return s.offset;
+}
+
+static int build_layout(const grip_dims& D, Layout& L) {
+    GRIP_REQUIRE(D.kind == 0 || D.kind == 1, "dims.kind must be 0 (vision) or 1 (text)");
+    GRIP_REQUIRE(D.width > 0 && D.width % 128 == 0 && D.heads * 64 == D.width, "width must be a multiple of 128 with head dim 64 (width=%d heads=%d)", D.width, D.heads);
+    GRIP_REQUIRE(D.embed_dim > 0 && D.embed_dim % 128 == 0, "embed_dim must be a multiple of 128");
+    GRIP_REQUIRE(D.layers > 0 && D.seq0 > 0, "layers / seq0 must be positive");
+    const int64_t d = D.width;
+    if (D.kind == 0) {
+        GRIP_REQUIRE(D.patch > 0 && D.resolution % D.patch == 0, "vision: resolution %% patch != 0");
+        const int g = D.resolution / D.patch;
+        GRIP_REQUIRE(D.seq0 == g * g + 1, "vision: seq0 must be grid^2 + 1");
+        L.kpad = (int)round_up64(3 * D.patch * D.patch, 64);
+        L.conv_w = add_slot(L, "conv1.weight", 0, 0, d, 3 * D.patch * D.patch, L.kpad);
+        L.cls = add_slot(L, "class_embedding", 1, 0, 1, d);
+        L.pos = add_slot(L, "positional_embedding", 1, 0, D.seq0, d);
+        L.lnpre_g = add_slot(L, "ln_pre.weight", 1, 0, 1, d);
+        L.lnpre_b = add_slot(L, "ln_pre.bias", 1, 0, 1, d);
+    } else {
+        GRIP_REQUIRE(D.vocab > 0, "text: vocab must be positive");
+        L.tok = add_slot(L, "token_embedding.weight", 1, 0, D.vocab, d);
+        L.pos = add_slot(L, "positional_embedding", 1, 0, D.seq0, d);
+    }
+    L.layer.resize((size_t)D.layers);
+    for (int i = 0; i < D.layers; ++i) {
+        LayerW& w = L.layer[(size_t)i];
+        const std::string p = "transformer.resblocks." + std::to_string(i) + ".";
+        w.ln1_g = add_slot(L, p + "ln_1.weight", 1, 0, 1, d);
+        w.ln1_b = add_slot(L, p + "ln_1.bias", 1, 0, 1, d);
+        w.in_w = add_slot(L, p + "attn.in_proj_weight", 0, 0, 3 * d, d);
+        w.in_b = add_slot(L, p + "attn.in_proj_bias", 1, 0, 1, 3 * d);
+        w.out_w = add_slot(L, p + "attn.out_proj.weight", 0, 0, d, d);
+        w.out_b = add_slot(L, p + "attn.out_proj.bias", 1, 0, 1, d);
+        w.ln2_g = add_slot(L, p + "ln_2.weight", 1, 0, 1, d);
+        w.ln2_b = add_slot(L, p + "ln_2.bias", 1, 0, 1, d);
+        w.fc_w = add_slot(L, p + "mlp.c_fc.weight", 0, 0, 4 * d, d);
+        w.fc_b = add_slot(L, p + "mlp.c_fc.bias", 1, 0, 1, 4 * d);
+        w.proj_w = add_slot(L, p + "mlp.c_proj.weight", 0, 0, d, 4 * d);
+        w.proj_b = add_slot(L, p + "mlp.c_proj.bias", 1, 0, 1, d);
+        w.in_wT = add_slot(L, p + "attn.in_proj_weight#T", 0, 1, d, 3 * d);
+        w.out_wT = add_slot(L, p + "attn.out_proj.weight#T", 0, 1, d, d);
+        w.fc_wT = add_slot(L, p + "mlp.c_fc.weight#T", 0, 1, d, 4 * d);
+        w.proj_wT = add_slot(L, p + "mlp.c_proj.weight#T", 0, 1, 4 * d, d);
+    }
+    const char* lnf = D.kind == 0 ? "ln_post" : "ln_final";
+    L.lnpost_g = add_slot(L, std::string(lnf) + ".weight", 1, 0, 1, d);
+    L.lnpost_b = add_slot(L, std::string(lnf) + ".bias", 1, 0, 1, d);
+    const char* pj = D.kind == 0 ? "proj" : "text_projection";
+    L.proj = add_slot(L, pj, 0, 0, d, D.embed_dim);
+    L.projT = add_slot(L, std::string(pj) + "#T", 0, 1, D.embed_dim, d);
+    L.n16 = round_up64(L.n16, 64);
+    L.n32 = round_up64(L.n32, 64);
+    return GRIP_OK;
+}
+
+extern "C" int grip_layout_slot(const grip_dims* dims, int slot, grip_slot* out) {
+    GRIP_REQUIRE(dims && out, "layout_slot: null pointer");
+    try {
+        Layout L;
+        int rc = build_layout(*dims, L);
+        if (rc) return rc;
+        GRIP_REQUIRE(slot >= 0 && slot < (int)L.slots.size(), "layout_slot: slot %d past the end (%d)", slot, (int)L.slots.size());
+        *out = L.slots[(size_t)slot];
+        return GRIP_OK;
+    } catch (...) { grip_set_error("layout_slot: exception"); return GRIP_ERR_ARG; }
+}
+
+extern "C" int grip_layout_size(const grip_dims* dims, int64_t* n_f16, int64_t* n_f32) {
+    GRIP_REQUIRE(dims && n_f16 && n_f32, "layout_size: null pointer");
+    try {
+        Layout L;
+        int rc = build_layout(*dims, L);
+        if (rc) return rc;
+        *n_f16 = L.n16;
+        *n_f32 = L.n32;
+        return GRIP_OK;
+    } catch (...) { grip_set_error("layout_size: exception"); return GRIP_ERR_ARG; }
+}
+
+// ---------------------------------------------------------------------------------------------- handle
+struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, train) problem
+    int batch = 0, P = 0, train = 0, S = 0, M = 0;
+    int64_t Mp = 0;
+    float* x = nullptr;        // inference residual stream
+    half_t* xn = nullptr;
+    half_t* qkv = nullptr;
+    half_t* att = nullptr;
+    half_t* h = nullptr;
+    half_t* cls16 = nullptr;   // [round_up(batch,128), d]
+    half_t* patches = nullptr; // alias of h
+    float* patch_out = nullptr;// alias of qkv
+    // train-mode saves, one per layer (x_in has layers+1 entries)
+    std::vector<float*> x_in, x_mid;
+    std::vector<half_t*> qkv_l, att_l, hpre_l;
+    // backward scratch
+    float* dx = nullptr;
+    float* dln = nullptr;
+    half_t* dxh = nullptr;
+    half_t* dh = nullptr;
+    half_t* dqkv = nullptr;
+    half_t* datt = nullptr;
+    float* dcls = nullptr;     // [round_up(batch,128), d] f32
+    half_t* gemb16 = nullptr;  // [round_up(batch,128), E] f16
+    float* scale = nullptr;    // [2] loss scale and its inverse
+    size_t bytes = 0;
+};
+
+struct grip_tower {
+    grip_dims D;
+    Layout L;
+    half_t* w16;
+    float* w32;
+    bool finalized = false;
+    // state of the last train-mode forward (for backward)
+    Workspace last;
+    void* last_ws = nullptr;
+    const int32_t* last_eot = nullptr;
+    int last_prefix_classes = 0;
+};
+
+static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w) {
+    const grip_dims& D = t->D;
+    GRIP_REQUIRE(batch > 0 && P >= 0 && P <= D.max_prefix, "batch must be positive and 0 <= n_prefix <= max_prefix (batch=%d n_prefix=%d max=%d)", batch, P, D.max_prefix);
+    const int64_t d = D.width;
+    w.batch = batch; w.P = P; w.train = train;
+    w.S = D.kind == 0 ? D.seq0 + P : D.seq0;
+    GRIP_REQUIRE(D.kind == 0 || P < D.seq0 - 1, "text: n_prefix %d does not fit the context", P);
+    GRIP_REQUIRE(w.S <= 608, "sequence length %d exceeds the fused-attention limit 608", w.S);
+    w.M = batch * w.S;
+    w.Mp = round_up64(w.M, 128);
+    const int64_t Bp = round_up64(batch, 128);
+    size_t off = 0;
+    auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return (void*)p; };
+    if (!train) w.x = (float*)take(w.Mp * d * 4);
+    w.xn = (half_t*)take(w.Mp * d * 2);
+    if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * 2); w.att = (half_t*)take(w.Mp * d * 2); }
+    w.h = (half_t*)take(w.Mp * 4 * d * 2);
+    w.cls16 = (half_t*)take(Bp * d * 2);
+    if (D.kind == 0) {
+        const int64_t G2 = D.seq0 - 1;
+        const int64_t prow = round_up64(batch * G2, 128);
+        GRIP_REQUIRE(prow * t->L.kpad <= w.Mp * 4 * d, "internal: patch buffer does not fit its alias");
+        w.patches = w.h;
+        w.patch_out = (float*)take(batch * G2 * d * 4);
+    }
+    if (train) {
+        const int Lc = D.layers;
+        w.x_in.assign((size_t)Lc + 1, nullptr); w.x_mid.assign((size_t)Lc, nullptr);
+        w.qkv_l.assign((size_t)Lc, nullptr); w.att_l.assign((size_t)Lc, nullptr); w.hpre_l.assign((size_t)Lc, nullptr);
+        for (int i = 0; i <= Lc; ++i) w.x_in[(size_t)i] = (float*)take(w.Mp * d * 4);
+        for (int i = 0; i < Lc; ++i) {
+            w.x_mid[(size_t)i] = (float*)take(w.Mp * d * 4);
+            w.qkv_l[(size_t)i] = (half_t*)take(w.Mp * 3 * d * 2);
+            w.att_l[(size_t)i] = (half_t*)take(w.Mp * d * 2);
+            w.hpre_l[(size_t)i] = (half_t*)take(w.Mp * 4 * d * 2);
+        }
+        w.dx = (float*)take(w.Mp * d * 4);
+        w.dln = (float*)take(w.Mp * d * 4);
+        w.dxh = (half_t*)take(w.Mp * d * 2);
+        w.dh = (half_t*)take(w.Mp * 4 * d * 2);
+        w.dqkv = (half_t*)take(w.Mp * 3 * d * 2);
+        w.datt = (half_t*)take(w.Mp * d * 2);
+        w.dcls = (float*)take(Bp * d * 4);
+        w.gemb16 = (half_t*)take(Bp * D.embed_dim * 2);
+        w.scale = (float*)take(256);
+    }
+    w.bytes = off;
+    return GRIP_OK;
+}
+
+extern "C" int grip_tower_create(const grip_dims* dims, void* f16_blob, void* f32_blob, grip_tower** out) {
+    GRIP_REQUIRE(dims && f16_blob && f32_blob && out, "tower_create: null pointer");
+    try {
+        grip_tower* t = new grip_tower();
+        t->D = *dims;
+        int rc = build_layout(*dims, t->L);
+        if (rc) { delete t; return rc; }
+        t->w16 = (half_t*)f16_blob;
+        t->w32 = (float*)f32_blob;
+        *out = t;
+        return GRIP_OK;
+    } catch (...) { grip_set_error("tower_create: exception"); return GRIP_ERR_ARG; }
+}
+
+extern "C" int grip_tower_destroy(grip_tower* t) {
+    delete t;
+    return GRIP_OK;
+}
+
+extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
+    GRIP_REQUIRE(t, "tower_finalize: null handle");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = t->D.width;
+    int rc;
+    for (const LayerW& w : t->L.layer) {
+        if ((rc = launch_transpose_f16(t->w16 + w.in_w, t->w16 + w.in_wT, 3 * d, d, d, s))) return rc;
+        if ((rc = launch_transpose_f16(t->w16 + w.out_w, t->w16 + w.out_wT, d, d, d, s))) return rc;
+        if ((rc = launch_transpose_f16(t->w16 + w.fc_w, t->w16 + w.fc_wT, 4 * d, d, d, s))) return rc;
+        if ((rc = launch_transpose_f16(t->w16 + w.proj_w, t->w16 + w.proj_wT, d, 4 * d, 4 * d, s))) return rc;
+    }
+    if ((rc = launch_transpose_f16(t->w16 + t->L.proj, t->w16 + t->L.projT, d, t->D.embed_dim, t->D.embed_dim, s))) return rc;
+    t->finalized = true;
+    return GRIP_OK;
+}
+
+extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int train, size_t* bytes) {
+    GRIP_REQUIRE(t && bytes, "workspace_bytes: null pointer");
+    try {
+        Workspace w;
+        int rc = carve(t, batch, n_prefix, train, nullptr, w);
+        if (rc) return rc;
+        *bytes = w.bytes;
+        return GRIP_OK;
+    } catch (...) { grip_set_error("workspace_bytes: exception"); return GRIP_ERR_ARG; }
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+static int run_blocks(grip_tower* t, Workspace& w, float* x0, int causal, hipStream_t s, float** x_final) {
+    const int d = t->D.width, H = t->D.heads;
+    const half_t* W = t->w16;
+    const float* F = t->w32;
+    float* x = x0;
+    for (int l = 0; l < t->D.layers; ++l) {
+        const LayerW& lw = t->L.layer[(size_t)l];
+        half_t* qkv = w.train ? w.qkv_l[(size_t)l] : w.qkv;
+        half_t* att = w.train ? w.att_l[(size_t)l] : w.att;
+        float* x_mid = w.train ? w.x_mid[(size_t)l] : x;
+        float* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
+        RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, w.M, d, s));
+        GemmArgs a{};
+        a.A = w.xn; a.W = W + lw.in_w; a.M = w.M; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
+        RUN(launch_gemm(EPI_BIAS_F16, a, s));
+        RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
+        a = GemmArgs{};
+        a.A = att; a.W = W + lw.out_w; a.M = w.M; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
+        RUN(launch_gemm(EPI_BIAS_RESID_F32, a, s));
+        RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, w.M, d, s));
+        a = GemmArgs{};
+        a.A = w.xn; a.W = W + lw.fc_w; a.M = w.M; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.h; a.ldc = 4 * d;
+        a.out2 = w.train ? w.hpre_l[(size_t)l] : nullptr;
+        RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
+        a = GemmArgs{};
+        a.A = w.h; a.W = W + lw.proj_w; a.M = w.M; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
+        RUN(launch_gemm(EPI_BIAS_RESID_F32, a, s));
+        x = x_out;
+    }
+    *x_final = x;
+    return GRIP_OK;
+}
+
+static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t ws_bytes, Workspace& w) {
+    GRIP_REQUIRE(t && ws, "null tower / workspace");
+    if (!t->finalized) { grip_set_error("tower not finalized: call grip_tower_finalize after filling the weight blobs"); return GRIP_ERR_STATE; }
+    RUN(carve(t, batch, P, train, (char*)ws, w));
+    if (w.bytes > ws_bytes) { grip_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes); return GRIP_ERR_WORKSPACE; }
+    GRIP_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+    return GRIP_OK;
+}
+
+extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f16, const float* prefix, int n_prefix,
+                                int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, void* stream) {
+    try {
+        GRIP_REQUIRE(t && t->D.kind == 0, "vit_forward: not a vision tower");
+        GRIP_REQUIRE(images && out_emb && (n_prefix == 0 || prefix), "vit_forward: null pointer");
+        Workspace w;
+        RUN(check_ws(t, batch, n_prefix, train, workspace, workspace_bytes, w));
+        hipStream_t s = (hipStream_t)stream;
+        const grip_dims& D = t->D;
+        const int d = D.width, G2 = D.seq0 - 1;
+        const half_t* W = t->w16;
+        const float* F = t->w32;
+        RUN(launch_im2col(images, images_f16, w.patches, batch, D.resolution, D.patch, t->L.kpad, s));
+        GemmArgs a{};
+        a.A = w.patches; a.W = W + t->L.conv_w; a.M = batch * G2; a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
+        RUN(launch_gemm(EPI_F32, a, s));
+        float* x0 = train ? w.x_in[0] : w.x;
+        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, batch, G2, d, s));
+        float* xf = nullptr;
+        RUN(run_blocks(t, w, x0, /*causal=*/0, s, &xf));
+        RUN(launch_gather_ln_f16(xf, nullptr, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, batch, d, s));
+        a = GemmArgs{};
+        a.A = w.cls16; a.W = W + t->L.projT; a.M = batch; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
+        RUN(launch_gemm(EPI_F32, a, s));
+        if (train) { t->last = w; t->last_ws = workspace; } else if (t->last_ws == workspace) { t->last_ws = nullptr; }
+        return GRIP_OK;
+    } catch (...) { grip_set_error("vit_forward: exception"); return GRIP_ERR_ARG; }
+}
+
+extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
+                                 int n_prefix, int prefix_classes, int n_class, float* out_emb,
+                                 void* workspace, size_t workspace_bytes, int train, void* stream) {
+    try {
+        GRIP_REQUIRE(t && t->D.kind == 1, "text_forward: not a text tower");
+        GRIP_REQUIRE(token_ids && eot_index && out_emb && (n_prefix == 0 || prefix), "text_forward: null pointer");
+        GRIP_REQUIRE(n_prefix == 0 || prefix_classes == 1 || prefix_classes == n_class, "text_forward: prefix_classes must be 1 or n_class");
+        Workspace w;
+        RUN(check_ws(t, n_class, n_prefix, train, workspace, workspace_bytes, w));
+        hipStream_t s = (hipStream_t)stream;
+        const grip_dims& D = t->D;
+        const int d = D.width;
+        const half_t* W = t->w16;
+        const float* F = t->w32;
+        float* x0 = train ? w.x_in[0] : w.x;
+        RUN(launch_text_embed(token_ids, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, n_class, D.seq0, d, D.vocab, s));
+        float* xf = nullptr;
+        RUN(run_blocks(t, w, x0, /*causal=*/1, s, &xf));
+        RUN(launch_gather_ln_f16(xf, eot_index, D.seq0, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, n_class, d, s));
+        GemmArgs a{};
+        a.A = w.cls16; a.W = W + t->L.projT; a.M = n_class; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
+        RUN(launch_gemm(EPI_F32, a, s));
+        if (train) { t->last = w; t->last_ws = workspace; t->last_eot = eot_index; t->last_prefix_classes = prefix_classes; }
+        else if (t->last_ws == workspace) { t->last_ws = nullptr; }
+        return GRIP_OK;
+    } catch (...) { grip_set_error("text_forward: exception"); return GRIP_ERR_ARG; }
+}
+
+// ---------------------------------------------------------------------------------------------- test hooks
+// Kernel-level entry points for the unit parity tests (tests/test_gpu_kernels.py).  Not part of the
+// drop-in ABI (not declared in include/grip_amd.h); they launch exactly the kernels the towers use.
+extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const float* resid,
+                               const void* aux, void* out, void* out2, float scalar, void* stream) {
+    GemmArgs a{};
+    a.A = (const half_t*)A; a.W = (const half_t*)W; a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid;
+    a.aux = (const half_t*)aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
+    return launch_gemm(epi, a, (hipStream_t)stream);
+}
+extern "C" int grip_debug_attention(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
+    return launch_attention_fwd((const half_t*)qkv, (half_t*)out, B, S, H, causal, (hipStream_t)stream);
+}
+extern "C" int grip_debug_layernorm(const float* x, const float* gamma, const float* beta, void* out, int M, int d, void* stream) {
+    return launch_layernorm_f16(x, gamma, beta, (half_t*)out, M, d, (hipStream_t)stream);
+}

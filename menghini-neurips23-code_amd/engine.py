@@ -1,0 +1,284 @@
+"""Host side of the native towers: weight blobs, handles, workspaces, autograd glue.
+
+torch is used for device memory, streams and autograd bookkeeping only; every FLOP of the
+encoders, the head and the losses runs in libgrip_amd.so (csrc/*.hip).
+"""
+import ctypes
+from ctypes import byref, c_int64, c_size_t, c_void_p
+
+import torch
+
+from . import native
+from .config import ClipDims
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(device):
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise native.GripError(
+            "grip_amd runs only on an AMD GPU (device 'cuda' under PyTorch-ROCm); there is no CPU path. "
+            f"Requested device: {device}")
+    return device
+
+
+class Tower:
+    """One frozen CLIP tower (vision or text) living in two HBM blobs behind a native handle."""
+
+    def __init__(self, kind, width, layers, heads, embed_dim, seq0, patch=0, resolution=0, vocab=0,
+                 max_prefix=64, device="cuda"):
+        self.device = require_gpu(device)
+        self.lib = native.lib()
+        self.dims = native.Dims(kind, width, layers, heads, embed_dim, seq0, patch, resolution, vocab, max_prefix)
+        self.kind, self.width, self.embed_dim, self.seq0 = kind, width, embed_dim, seq0
+        n16, n32 = c_int64(), c_int64()
+        native.check(self.lib.grip_layout_size(byref(self.dims), byref(n16), byref(n32)))
+        self.blob16 = torch.zeros(n16.value, dtype=torch.float16, device=self.device)
+        self.blob32 = torch.zeros(n32.value, dtype=torch.float32, device=self.device)
+        self.slots = {}
+        s, i = native.Slot(), 0
+        while self.lib.grip_layout_slot(byref(self.dims), i, byref(s)) == 0:
+            self.slots[s.name.decode()] = (s.dtype, s.derived, s.offset, s.rows, s.cols, s.ld)
+            i += 1
+        h = c_void_p()
+        native.check(self.lib.grip_tower_create(byref(self.dims), _ptr(self.blob16), _ptr(self.blob32), byref(h)))
+        self.handle = h
+        self._ws = {}
+        self._finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.grip_tower_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- weights
+    def primary_names(self):
+        return [n for n, v in self.slots.items() if not v[1]]
+
+    def view(self, name):
+        """Tensor view (rows x cols, row stride ld) of a slot inside its blob."""
+        dtype, _, off, rows, cols, ld = self.slots[name]
+        blob = self.blob16 if dtype == 0 else self.blob32
+        return blob.as_strided((rows, cols), (ld, 1), off)
+
+    def load(self, name, tensor):
+        v = self.view(name)
+        v.copy_(tensor.reshape(v.shape).to(device=self.device, dtype=v.dtype))
+        self._finalized = False
+
+    def finalize(self):
+        native.check(self.lib.grip_tower_finalize(self.handle, _stream()))
+        self._finalized = True
+
+    # ---- workspaces
+    def workspace(self, batch, n_prefix, train):
+        key = (batch, n_prefix, bool(train))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = c_size_t()
+            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, int(train), byref(nbytes)))
+            if not train:   # inference workspaces are interchangeable: keep only the largest
+                for k in [k for k in self._ws if not k[2]]:
+                    if self._ws[k].numel() >= nbytes.value:
+                        return self._ws[k]
+                    del self._ws[k]
+            ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    @staticmethod
+    def _aligned(ws):
+        off = (-ws.data_ptr()) % 256
+        return c_void_p(ws.data_ptr() + off), ws.numel() - off
+
+    # ---- forward / backward
+    def vit_forward(self, images, prefix=None, train=False):
+        if not self._finalized:
+            self.finalize()
+        assert self.kind == 0
+        images = images.contiguous()
+        if images.dtype not in (torch.float32, torch.float16):
+            images = images.float()
+        B = images.shape[0]
+        P = 0 if prefix is None else prefix.shape[-2]
+        if prefix is not None:
+            prefix = prefix.reshape(P, self.width).contiguous().float()
+        out = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, P, train)
+        p, n = self._aligned(ws)
+        native.check(self.lib.grip_vit_forward(self.handle, _ptr(images), int(images.dtype == torch.float16), _ptr(prefix), P, B,
+                                               _ptr(out), p, n, int(train), _stream()))
+        return out, ws
+
+    def vit_backward(self, grad_emb, prefix, ws):
+        P = prefix.shape[-2]
+        prefix = prefix.reshape(P, self.width).contiguous().float()
+        grad_emb = grad_emb.contiguous().float()
+        g = torch.empty(P, self.width, dtype=torch.float32, device=self.device)
+        p, n = self._aligned(ws)
+        native.check(self.lib.grip_vit_backward_prefix(self.handle, _ptr(grad_emb), _ptr(prefix), _ptr(g), p, n, _stream()))
+        return g
+
+    def text_forward(self, token_ids, prefix=None, train=False):
+        if not self._finalized:
+            self.finalize()
+        assert self.kind == 1
+        ids = token_ids.to(device=self.device, dtype=torch.int32).contiguous()
+        eot = ids.argmax(dim=-1).to(torch.int32).contiguous()
+        C = ids.shape[0]
+        P, pc = 0, 1
+        if prefix is not None:
+            pc, P = prefix.shape[0], prefix.shape[1]
+            prefix = prefix.contiguous().float()
+        out = torch.empty(C, self.embed_dim, dtype=torch.float32, device=self.device)
+        ws = self.workspace(C, P, train)
+        p, n = self._aligned(ws)
+        native.check(self.lib.grip_text_forward(self.handle, _ptr(ids), _ptr(eot), _ptr(prefix), P, pc, C, _ptr(out), p, n,
+                                                int(train), _stream()))
+        return out, ws, (ids, eot)
+
+    def text_backward(self, grad_emb, prefix_shape, ws):
+        grad_emb = grad_emb.contiguous().float()
+        g = torch.empty(prefix_shape, dtype=torch.float32, device=self.device)
+        p, n = self._aligned(ws)
+        native.check(self.lib.grip_text_backward_prefix(self.handle, _ptr(grad_emb), _ptr(g), p, n, _stream()))
+        return g
+
+
+def vision_tower(d: ClipDims, device="cuda", max_prefix=64):
+    return Tower(0, d.vision_width, d.vision_layers, d.vision_heads, d.embed_dim, d.vision_seq, d.vision_patch_size,
+                 d.image_resolution, 0, max_prefix, device)
+
+
+def text_tower(d: ClipDims, device="cuda", max_prefix=64):
+    return Tower(1, d.transformer_width, d.transformer_layers, d.transformer_heads, d.embed_dim, d.context_length, 0, 0,
+                 d.vocab_size, max_prefix, device)
+
+
+# ------------------------------------------------------------------------------------------ autograd
+class VitPrefixFn(torch.autograd.Function):
+    """CustomVisionTransformer.forward with autograd to the visual prompt only (frozen backbone)."""
+
+    @staticmethod
+    def forward(ctx, tower, images, prefix):
+        need = prefix.requires_grad and torch.is_grad_enabled()
+        out, ws = tower.vit_forward(images, prefix.detach(), train=need)
+        ctx.tower, ctx.ws = tower, ws
+        ctx.save_for_backward(prefix.detach())
+        ctx.pshape, ctx.pdtype = prefix.shape, prefix.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (prefix,) = ctx.saved_tensors
+        g = ctx.tower.vit_backward(grad_out, prefix, ctx.ws)
+        return None, None, g.reshape(ctx.pshape).to(ctx.pdtype)
+
+
+class TextPrefixFn(torch.autograd.Function):
+    """CustomTextEncoder.forward with autograd to the textual prompt only."""
+
+    @staticmethod
+    def forward(ctx, tower, token_ids, prefix):
+        need = prefix.requires_grad and torch.is_grad_enabled()
+        out, ws, _ = tower.text_forward(token_ids, prefix.detach(), train=need)
+        ctx.tower, ctx.ws = tower, ws
+        ctx.pshape, ctx.pdtype = prefix.shape, prefix.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.tower.text_backward(grad_out, tuple(ctx.pshape), ctx.ws)
+        return None, None, g.to(ctx.pdtype)
+
+
+def cosine_head(img_emb, txt_emb, scale, want_probs=True):
+    """normalize -> scale * img @ txt.T -> softmax / argmax, fused (no autograd)."""
+    lib = native.lib()
+    img = img_emb.detach().contiguous().float()
+    txt = txt_emb.detach().contiguous().float()
+    n, e = img.shape
+    c = txt.shape[0]
+    dev = img.device
+    logits = torch.empty(n, c, dtype=torch.float32, device=dev)
+    probs = torch.empty(n, c, dtype=torch.float32, device=dev) if want_probs else None
+    am_l = torch.empty(n, dtype=torch.int32, device=dev)
+    am_p = torch.empty(n, dtype=torch.int32, device=dev) if want_probs else None
+    scratch = torch.empty(c, e, dtype=torch.float32, device=dev)
+    native.check(lib.grip_cosine_head(_ptr(img), _ptr(txt), float(scale), n, c, e, _ptr(logits), _ptr(probs), _ptr(am_l), _ptr(am_p),
+                                      _ptr(scratch), _stream()))
+    return logits, probs, am_l, am_p
+
+
+class CosineHeadFn(torch.autograd.Function):
+    """logits = scale * normalize(img) @ normalize(txt).T with native forward and backward."""
+
+    @staticmethod
+    def forward(ctx, img_emb, txt_emb, scale):
+        logits, _, _, _ = cosine_head(img_emb, txt_emb, scale, want_probs=False)
+        ctx.save_for_backward(img_emb.detach(), txt_emb.detach())
+        ctx.scale = float(scale)
+        ctx.need = (img_emb.requires_grad, txt_emb.requires_grad)
+        return logits
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        img, txt = ctx.saved_tensors
+        lib = native.lib()
+        img = img.contiguous().float()
+        txt = txt.contiguous().float()
+        n, e = img.shape
+        c = txt.shape[0]
+        g = grad_logits.contiguous().float()
+        gi = torch.empty_like(img) if ctx.need[0] else None
+        gt = torch.empty_like(txt) if ctx.need[1] else None
+        native.check(lib.grip_cosine_head_backward(_ptr(img), _ptr(txt), ctx.scale, n, c, e, _ptr(g), _ptr(gi), _ptr(gt), _stream()))
+        return gi, gt, None
+
+
+class WeightedCEFn(torch.autograd.Function):
+    """sum_i w_i * CE(logits_i, label_i), native forward+backward (one kernel produces both)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, row_weight):
+        lib = native.lib()
+        lg = logits.contiguous().float()
+        n, c = lg.shape
+        lab = labels.to(device=lg.device, dtype=torch.int32).contiguous()
+        w = row_weight.to(device=lg.device, dtype=torch.float32).contiguous()
+        loss = torch.zeros(1, dtype=torch.float32, device=lg.device)
+        grad = torch.empty_like(lg)
+        native.check(lib.grip_weighted_ce(_ptr(lg), _ptr(lab), _ptr(w), n, c, _ptr(loss), _ptr(grad), _stream()))
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def leaderboard_scan(probs, pred, path_rank, k):
+    """Host scan (exact, sequential).  probs [n,c] f32 CPU, pred [n] int32 CPU, path_rank [n] int64 CPU."""
+    import numpy as np
+    lib = native.lib()
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    pred = np.ascontiguousarray(pred, dtype=np.int32)
+    rank = np.ascontiguousarray(path_rank, dtype=np.int64)
+    n, c = probs.shape
+    cap = c * max(1, min(int(k), n))
+    out_img = np.empty(cap, dtype=np.int32)
+    out_cls = np.empty(cap, dtype=np.int32)
+    m = c_int64()
+    native.check(lib.grip_leaderboard_scan(c_void_p(probs.ctypes.data), c_void_p(pred.ctypes.data), c_void_p(rank.ctypes.data),
+                                           n, c, int(k), c_void_p(out_img.ctypes.data), c_void_p(out_cls.ctypes.data), byref(m)))
+    return out_img[: m.value].copy(), out_cls[: m.value].copy()

@@ -1,0 +1,84 @@
+"""Prompt models with the reference's names, constructor/forward signatures and parameter names
+(models/prompts_models.py): they own the only trainable tensors."""
+import logging
+
+import torch
+from torch import nn
+
+from .. import clip
+
+log = logging.getLogger(__name__)
+
+
+class _ModuleShim:
+    """Reference callers reach `.module.classes` whenever torch.cuda.is_available() (DDP-wrapped
+    model, e.g. methods/semi_supervised_learning/textual_prompt.py:94-97); PyTorch-ROCm reports
+    cuda available, so an un-wrapped model must answer to `.module` too."""
+
+    @property
+    def module(self):
+        return self
+
+
+class TextPrefixModel(_ModuleShim, nn.Module):
+    def __init__(self, initial_prefix, text_encoder, classes, temperature=0.07, device="cpu"):
+        super().__init__()
+        self.device = device
+        self.initialized_prefix = initial_prefix
+        self.classes = classes
+        self.prefix = nn.Parameter(initial_prefix)
+        self.text_encoder = text_encoder
+
+    def forward(self, classes):
+        return self.text_encoder(self.prefix, classes)     # un-normalised, as reference :31-36
+
+
+class ImagePrefixModel(_ModuleShim, nn.Module):
+    def __init__(self, initial_prefix, image_encoder, temperature=0.07, device="cpu"):
+        super().__init__()
+        self.device = device
+        self.initialized_prefix = initial_prefix
+        self.prefix = nn.Parameter(initial_prefix)
+        self.image_encoder = image_encoder
+
+    def forward(self, x):
+        return self.image_encoder(x, self.prefix)          # un-normalised, as reference :55-61
+
+
+class UPTModel(_ModuleShim, nn.Module):
+    def __init__(self, coop_embeddings, vpt_embeddings, vpt_embeddings_deep, image_encoder, text_encoder, classes,
+                 dim_transformer, temperature=0.07, device="cpu", dtype=torch.float32):
+        super().__init__()
+        self.device = device
+        self.classes = classes
+        self.temperature = temperature
+        self.dtype = dtype
+        self.coop_embeddings = nn.Parameter(coop_embeddings)
+        self.vpt_embeddings = nn.Parameter(vpt_embeddings)
+        self.coop_length, self.coop_dim = self.coop_embeddings.size()[1], self.coop_embeddings.size()[2]
+        self.vpt_length, self.vpt_dim = self.vpt_embeddings.size()[1], self.vpt_embeddings.size()[2]
+        self.vpt_embeddings_deep = nn.Parameter(vpt_embeddings_deep) if vpt_embeddings_deep is not None else None
+        self.proj_coop_pre = nn.Linear(self.coop_dim, dim_transformer, dtype=self.dtype).to(self.device)
+        self.proj_coop_post = nn.Linear(dim_transformer, self.coop_dim, dtype=self.dtype).to(self.device)
+        self.proj_vpt_pre = nn.Linear(self.vpt_dim, dim_transformer, dtype=self.dtype).to(self.device)
+        self.proj_vpt_post = nn.Linear(dim_transformer, self.vpt_dim, dtype=self.dtype).to(self.device)
+        self.transformer = clip.model.Transformer(width=dim_transformer, layers=1, heads=1).to(self.device)
+        self.image_encoder = image_encoder
+        self.text_encoder = text_encoder
+
+    def mix(self):
+        """Reference :129-146 (incl. the fp32 -> fp16 -> dtype round trip of :138-145)."""
+        coop = self.proj_coop_pre(self.coop_embeddings)
+        vpt = self.proj_vpt_pre(self.vpt_embeddings)
+        seq = torch.cat((coop, vpt), dim=0).to(torch.float32)
+        out = self.transformer(seq).to(torch.float16)
+        n = len(self.coop_embeddings)
+        coop_embs = self.proj_coop_post(out[:n].to(self.dtype)).reshape(-1, self.coop_length, self.coop_dim)
+        vpt_embs = self.proj_vpt_post(out[n:].to(self.dtype)).reshape(-1, self.vpt_length, self.vpt_dim)
+        return coop_embs, vpt_embs
+
+    def forward(self, x, classes):
+        coop_embs, vpt_embs = self.mix()
+        text_out = self.text_encoder(coop_embs, classes)
+        visual_out = self.image_encoder(x, vpt_embs)
+        return text_out, visual_out

@@ -1,0 +1,80 @@
+"""ctypes binding of the C ABI in include/grip_amd.h (libgrip_amd.so, built in-tree by
+`make -C menghini-neurips23-code_amd/csrc` / `__graft_entry__.build()`).
+
+There is no CPU fallback: if the library is missing or reports another ABI version every entry
+point raises.  Nothing here imports the oracle.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrip_amd.so")
+ABI_VERSION = 1
+
+
+class GripError(RuntimeError):
+    pass
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("kind", "width", "layers", "heads", "embed_dim", "seq0", "patch",
+                                       "resolution", "vocab", "max_prefix")]
+
+
+class Slot(ctypes.Structure):
+    _fields_ = [("name", c_char * 96), ("dtype", c_int32), ("derived", c_int32), ("offset", c_int64),
+                ("rows", c_int64), ("cols", c_int64), ("ld", c_int64)]
+
+
+_SIGS = {
+    "grip_last_error": (ctypes.c_char_p, []),
+    "grip_abi_version": (c_int, []),
+    "grip_layout_slot": (c_int, [POINTER(Dims), c_int, POINTER(Slot)]),
+    "grip_layout_size": (c_int, [POINTER(Dims), POINTER(c_int64), POINTER(c_int64)]),
+    "grip_tower_create": (c_int, [POINTER(Dims), c_void_p, c_void_p, POINTER(c_void_p)]),
+    "grip_tower_finalize": (c_int, [c_void_p, c_void_p]),
+    "grip_tower_destroy": (c_int, [c_void_p]),
+    "grip_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "grip_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "grip_vit_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "grip_text_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "grip_text_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "grip_cosine_head": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "grip_cosine_head_backward": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "grip_weighted_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "grip_leaderboard_scan": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
+}
+EXPORTS = tuple(_SIGS)   # the drop-in ABI (include/grip_amd.h)
+_DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of the ABI
+    "grip_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "grip_debug_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "grip_debug_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises GripError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GripError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C menghini-neurips23-code_amd/csrc`). "
+                "There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in {**_SIGS, **_DEBUG_SIGS}.items():
+            fn = getattr(l, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if l.grip_abi_version() != ABI_VERSION:
+            raise GripError(f"libgrip_amd.so ABI {l.grip_abi_version()} != host layer ABI {ABI_VERSION}; rebuild")
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise GripError(f"grip_amd native call failed (status {rc}): {lib().grip_last_error().decode()}")

@@ -1,0 +1,121 @@
+"""Kernel-level numerics: each HIP kernel against a plain PyTorch fp32 reference of the same op
+(inputs rounded to f16 where the kernel consumes f16, so the comparison isolates the kernel)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _lib():
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    return native, native.lib()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (3408, 2304, 768), (77 * 5, 512, 2048), (16, 512, 768)])
+def test_gemm_epilogues(M, N, K):
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    Mp = (M + 127) // 128 * 128
+    A = torch.randn(Mp, K, device="cuda", generator=g).half()
+    A[M:] = float("nan")  # padding rows must never leak into stored rows
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g)
+    aux = torch.randn(M, N, device="cuda", generator=g).half()
+    ref = A[:M].float() @ W.float().t()
+    tol = dict(rtol=2e-3, atol=2e-3)
+
+    out = torch.full((M, N), 7.0, device="cuda")
+    native.check(lib.grip_debug_gemm(0, _p(A), _p(W), M, N, K, None, None, None, _p(out), None, 1.0, _stream()))
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)   # EPI_F32: only f32 summation order differs
+
+    out16 = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_gemm(1, _p(A), _p(W), M, N, K, _p(bias), None, None, _p(out16), None, 1.0, _stream()))
+    torch.testing.assert_close(out16.float(), ref + bias, **tol)
+
+    pre = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_gemm(2, _p(A), _p(W), M, N, K, _p(bias), None, None, _p(out16), _p(pre), 1.0, _stream()))
+    torch.testing.assert_close(out16.float(), quick_gelu(ref + bias), **tol)
+    torch.testing.assert_close(pre.float(), ref + bias, **tol)
+
+    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), None, _p(out), None, 1.0, _stream()))
+    torch.testing.assert_close(out, ref + bias + resid, rtol=1e-4, atol=1e-4)
+    # in place (out aliases resid), as the inference path uses it
+    r2 = resid.clone()
+    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(r2), None, _p(r2), None, 1.0, _stream()))
+    torch.testing.assert_close(r2, ref + bias + resid, rtol=1e-4, atol=1e-4)
+
+    native.check(lib.grip_debug_gemm(5, _p(A), _p(W), M, N, K, None, None, _p(aux), _p(out16), None, 1.0, _stream()))
+    x = aux.float()
+    s = torch.sigmoid(1.702 * x)
+    torch.testing.assert_close(out16.float(), ref * (s * (1 + 1.702 * x * (1 - s))), **tol)
+
+
+def test_gemm_is_not_transposed():
+    """A = I, asymmetric W: catches an output / operand transpose."""
+    native, lib = _lib()
+    A = torch.eye(128, device="cuda").half()
+    W = (torch.arange(128 * 128, device="cuda").reshape(128, 128) % 97).half()
+    out = torch.zeros(128, 128, device="cuda")
+    native.check(lib.grip_debug_gemm(0, _p(A), _p(W), 128, 128, 128, None, None, None, _p(out), None, 1.0, _stream()))
+    torch.testing.assert_close(out, W.float().t())
+
+
+@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (3, 33, 2, 0), (2, 77, 8, 1), (2, 197, 12, 0), (2, 213, 12, 0), (1, 257, 4, 0), (1, 593, 2, 0)])
+def test_attention(B, S, H, causal):
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(S)
+    D = H * 64
+    qkv = (torch.randn(B * S, 3 * D, device="cuda", generator=g) * 1.5).half()
+    out = torch.zeros(B * S, D, device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_attention(_p(qkv), _p(out), B, S, H, causal, _stream()))
+    q, k, v = qkv.float().reshape(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((S, S), float("-inf"), device="cuda").triu(1)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    torch.testing.assert_close(out.float(), ref, rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("M,d", [(5, 128), (300, 512), (1000, 768), (64, 1024)])
+def test_layernorm(M, d):
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(d)
+    x = torch.randn(M, d, device="cuda", generator=g) * 3 + 1
+    gamma = torch.randn(d, device="cuda", generator=g)
+    beta = torch.randn(d, device="cuda", generator=g)
+    out = torch.zeros(M, d, device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_layernorm(_p(x), _p(gamma), _p(beta), _p(out), M, d, _stream()))
+    ref = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_cosine_head_matches_torch():
+    import grip_amd  # noqa: F401
+    from grip_amd import engine
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.randn(1000, 512, device="cuda", generator=g)
+    txt = torch.randn(102, 512, device="cuda", generator=g)
+    logits, probs, am_l, am_p = engine.cosine_head(img, txt, 100.0)
+    i = img / img.norm(dim=-1, keepdim=True)
+    t = txt / txt.norm(dim=-1, keepdim=True)
+    ref = 100.0 * i @ t.t()
+    torch.testing.assert_close(logits, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(probs, ref.softmax(-1), rtol=1e-3, atol=1e-6)
+    assert (am_l.long() == logits.argmax(1)).all()      # first-max-wins arg-max of its own logits: exact
+    assert (am_p.long() == probs.argmax(1)).all()

@@ -1,0 +1,129 @@
+"""Tower-level parity on the GPU: the native ViT / text towers (through the C ABI) against the
+committed golden vectors (outputs of the reference's own wrappers over the CPU oracle, produced by
+oracle/gen_golden.py) and against the CPU oracle on fresh seeded inputs.
+
+Tolerance: north_star asks for <= 1e-3 cosine distance on fp32 embeddings; we assert 1 - cos <= 1e-4
+and a relative L2 error <= 2e-2 (f16 operands, f32 accumulate / residual / LayerNorm / softmax)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-4
+REL_TOL = 2e-2
+SEED = 100
+
+
+def _inputs(name, shape, std=1.0):
+    import grip_amd  # noqa: F401
+    from grip_amd import rng
+    return torch.from_numpy(rng.normal(SEED, rng.stream_id(name), shape, 0.0, std))
+
+
+def assert_embeddings_close(got, want, what):
+    got = got.detach().float().cpu()
+    want = torch.as_tensor(np.asarray(want)).float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
+    rel = (got - want).norm() / want.norm()
+    assert (1 - cos).max().item() <= COS_TOL, f"{what}: 1-cos = {(1 - cos).max().item():.3e}"
+    assert rel.item() <= REL_TOL, f"{what}: relative L2 error {rel.item():.3e}"
+
+
+@pytest.fixture(scope="module")
+def models():
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = clip.load(name, device="cuda")[0]
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("tag,name,n_img,P", [("g1", "tiny", 3, 3), ("g1s", "small", 2, 16)])
+def test_golden_small_towers(models, golden_small, tag, name, n_img, P):
+    import grip_amd  # noqa: F401
+    from grip_amd import config
+    from grip_amd.models import CustomImageEncoder, CustomTextEncoder, TextEncoder
+    m = models(name)
+    d = config.get_dims(name)
+    x = _inputs(f"{tag}.x", (n_img, 3, d.image_resolution, d.image_resolution)).cuda()
+    vprefix = _inputs(f"{tag}.vprefix", (P, d.vision_width), 0.02).cuda()
+    tprefix = _inputs(f"{tag}.tprefix", (1, P, d.transformer_width), 0.02).cuda()
+    assert_embeddings_close(m.encode_image(x), golden_small[f"{tag}.vision_p0"], "encode_image")
+    assert_embeddings_close(CustomImageEncoder(m.visual)(x, vprefix), golden_small[f"{tag}.vision_p{P}"], "vision+prefix")
+    ztok = torch.from_numpy(golden_small[f"{tag}.zs_tokens"]).cuda()
+    assert_embeddings_close(TextEncoder(m)(ztok), golden_small[f"{tag}.text_p0"], "encode_text")
+    ctok = torch.from_numpy(golden_small[f"{tag}.coop_tokens"]).cuda()
+    out, _, _ = m.text_tower.text_forward(ctok, tprefix)
+    assert_embeddings_close(out, golden_small[f"{tag}.text_p{P}"], "text+prefix")
+    logits, _ = m(x, ztok)
+    want = torch.from_numpy(golden_small[f"{tag}.zs_logits"])
+    assert (logits.cpu() - want).abs().max().item() <= 0.05, (logits.cpu() - want).abs().max().item()
+
+
+def test_golden_vitb16(models, golden_vitb16):
+    """Full-size ViT-B/16 + text-B spot check (G3): weights regenerated from the seed on this box."""
+    import grip_amd  # noqa: F401
+    from grip_amd.models import CustomImageEncoder
+    m = models("ViT-B/16")
+    g = golden_vitb16
+    x = _inputs("g3.x", (2, 3, 224, 224)).cuda()
+    vprefix = _inputs("g3.vprefix", (16, 768), 0.02).cuda()
+    tprefix = _inputs("g3.tprefix", (1, 16, 512), 0.02).cuda()
+    assert_embeddings_close(m.encode_image(x), g["g3.vision_p0"], "B/16 encode_image")
+    assert_embeddings_close(CustomImageEncoder(m.visual)(x, vprefix), g["g3.vision_p16"], "B/16 vision+prefix")
+    assert_embeddings_close(m.encode_text(torch.from_numpy(g["g3.zs_tokens"]).cuda()), g["g3.text_p0"], "B/16 encode_text")
+    out, _, _ = m.text_tower.text_forward(torch.from_numpy(g["g3.coop_tokens"]).cuda(), tprefix)
+    assert_embeddings_close(out, g["g3.text_p16"], "B/16 text+prefix")
+    logits, _ = m(x, torch.from_numpy(g["g3.zs_tokens"]).cuda())
+    probs = logits.softmax(-1).cpu()
+    assert (probs - torch.from_numpy(g["g3.zs_probs"])).abs().max().item() <= 5e-3
+
+
+@pytest.mark.parametrize("name,B,P", [("tiny", 37, 0), ("small", 9, 4), ("small", 130, 16)])
+def test_vision_vs_oracle_fresh_inputs(models, name, B, P):
+    """Odd batch sizes (ragged GEMM tails) against the CPU oracle run here on the same inputs."""
+    from conftest import oracle_clip
+    from oracle import wrappers as W
+    import grip_amd  # noqa: F401
+    from grip_amd import config
+    d = config.get_dims(name)
+    om, _ = oracle_clip().load(name)
+    m = models(name)
+    x = _inputs(f"fresh.{name}.{B}", (B, 3, d.image_resolution, d.image_resolution))
+    prefix = _inputs(f"fresh.p.{name}.{P}", (P, d.vision_width), 0.05) if P else None
+    want = W.vision_forward(om.visual, x, prefix)
+    got = m.visual(x.cuda(), prefix.cuda() if P else None)
+    assert_embeddings_close(got, want.detach(), f"{name} B={B} P={P}")
+    # same images as f16 input
+    got16 = m.visual(x.cuda().half(), prefix.cuda() if P else None)
+    assert_embeddings_close(got16, want.detach(), f"{name} B={B} P={P} f16 images")
+
+
+@pytest.mark.parametrize("name,C,P,per_class", [("tiny", 1, 0, False), ("tiny", 11, 5, False), ("small", 7, 16, True)])
+def test_text_vs_oracle_fresh_inputs(models, name, C, P, per_class):
+    from conftest import oracle_clip
+    from oracle import wrappers as W
+    import grip_amd  # noqa: F401
+    from grip_amd import config, rng
+    d = config.get_dims(name)
+    om, _ = oracle_clip().load(name)
+    m = models(name)
+    ids = torch.zeros(C, 77, dtype=torch.int32)
+    for c in range(C):
+        n = 2 + (c * 5) % 9
+        body = rng.integers(SEED, rng.stream_id(f"tok{c}"), (n,), 1000, 40000)
+        row = [49406] + [343] * P + list(body) + [49407]
+        ids[c, : len(row)] = torch.tensor(row, dtype=torch.int32)
+    prefix = None
+    if P:
+        prefix = _inputs(f"fresh.tp.{name}.{P}.{per_class}", (C if per_class else 1, P, d.transformer_width), 0.05)
+    want = W.text_forward(om, ids, prefix)
+    got, _, _ = m.text_tower.text_forward(ids.cuda(), prefix.cuda() if P else None)
+    assert_embeddings_close(got, want.detach(), f"text {name} C={C} P={P}")
