@@ -1,0 +1,260 @@
+// Backward of the fused self-attention (input gradients only): dqkv from qkv, the saved output O
+// and dO.  One workgroup of 4 waves per (image, head); K and V of that head stay in LDS for both
+// phases, probabilities are RECOMPUTED from q, k (nothing but O was saved by the forward).
+//
+//   phase 1, per 16-row query tile (wave-parallel):  S^T = K (Q/8)^T, row max / sum  -> P^T;
+//            dP^T = V dO^T;  delta = rowsum(dO * O);  dS^T = P^T * (dP^T - delta);
+//            dQ^T = K^T dS^T / 8   (A = transposed K copy in LDS, B = packed dS registers);
+//            the row statistics (max, 1/sum, delta) go to LDS for phase 2.
+//   phase 2, per 16-row key tile (wave-parallel), looping over 32 queries at a time:
+//            S = (Q/8) K^T and dP = dO V^T recomputed in the [query][key] orientation, which puts
+//            the QUERY index on the MFMA contraction axis:  dV^T += dO^T P,  dK^T += (Q/8)^T dS
+//            (A = transposed dO / Q copies in LDS, B = packed P / dS registers).
+// All contractions are v_mfma_f32_16x16x32_f16; softmax statistics and dS are f32.
+#include <math.h>
+
+#include "common.h"
+
+template <int KVC, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ o_saved,
+                                                       const half_t* __restrict__ d_out, half_t* __restrict__ dqkv, int S, int H) {
+    constexpr int SP = KVC * 32;
+    constexpr int VST = SP + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* Ks = (half_t*)smem;          // [SP][64] swizzled rows
+    half_t* Vs = Ks + SP * 64;           // [SP][64] swizzled rows
+    half_t* T0 = Vs + SP * 64;           // [64][VST]: K^T in phase 1, (Q/8)^T in phase 2
+    half_t* T1 = T0 + 64 * VST;          // [64][VST]: dO^T (phase 2)
+    float* st_m = (float*)(T1 + 64 * VST);   // [SP] row max
+    float* st_il = st_m + SP;                // [SP] 1 / row sum
+    float* st_d = st_il + SP;                // [SP] delta
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int D = H * 64;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const size_t ld = (size_t)3 * D;
+    const half_t* base = qkv + (size_t)b * S * ld + h * 64;
+    const half_t* obase = o_saved + (size_t)b * S * D + h * 64;
+    const half_t* dobase = d_out + (size_t)b * S * D + h * 64;
+    half_t* dbase = dqkv + (size_t)b * S * ld + h * 64;
+
+    for (int idx = tid; idx < SP * 8; idx += 256) {
+        const int row = idx >> 3, chunk = idx & 7;
+        half8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < S) {
+            kv = *(const half8*)(base + row * ld + D + chunk * 8);
+            vv = *(const half8*)(base + row * ld + 2 * D + chunk * 8);
+        }
+        const int sw = (chunk ^ (row & 7)) * 8;
+        *(half8*)(Ks + row * 64 + sw) = kv;
+        *(half8*)(Vs + row * 64 + sw) = vv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T0[(chunk * 8 + j) * VST + row] = kv[j];
+    }
+    __syncthreads();
+
+    const int n_qt = (S + 15) >> 4;
+    // ------------------------------------------------------------------ phase 1: dQ and row statistics
+    for (int qt = wave; qt < n_qt; qt += 4) {
+        asm volatile("" ::: "memory");
+        const int qrow = qt * 16 + li;
+        const int qr = qrow < S ? qrow : S - 1;
+        half8 qf[2], dof[2];
+        float dl = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[kk] = *(const half8*)(base + qr * ld + (kk * 4 + lg) * 8);
+            qf[kk] *= (half_t)0.125f;
+            dof[kk] = *(const half8*)(dobase + (size_t)qr * D + (kk * 4 + lg) * 8);
+            const half8 of = *(const half8*)(obase + (size_t)qr * D + (kk * 4 + lg) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)dof[kk][j] * (float)of[j];
+        }
+        dl += __shfl_xor(dl, 16);
+        dl += __shfl_xor(dl, 32);
+
+        f32x4 sc[2 * KVC];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * KVC; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const half8 kf = *(const half8*)(Ks + (t * 16 + li) * 64 + (((kk * 4 + lg) ^ (lane & 7)) * 8));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kv = t * 16 + lg * 4 + r;
+                if (kv >= S || (CAUSAL && kv > qrow)) acc[r] = -INFINITY;
+                m = fmaxf(m, acc[r]);
+            }
+            sc[t] = acc;
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * KVC; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[t][r] - m);
+                sc[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float il = 1.0f / sum;
+        if (lg == 0 && qrow < SP) { st_m[qrow] = m; st_il[qrow] = il; st_d[qrow] = dl; }
+
+        // dS^T = P^T * (dP^T - delta), dP^T tile = V dO^T
+#pragma unroll
+        for (int t = 0; t < 2 * KVC; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const half8 vf = *(const half8*)(Vs + (t * 16 + li) * 64 + (((kk * 4 + lg) ^ (lane & 7)) * 8));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, dof[kk], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[t][r] = sc[t][r] * il * (acc[r] - dl);
+        }
+        // dQ^T[dh][q] = sum_kv K^T[dh][kv] dS^T[kv][q]
+        f32x4 dq[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) dq[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KVC; ++c) {
+            const half8 sf = {(half_t)sc[2 * c][0], (half_t)sc[2 * c][1], (half_t)sc[2 * c][2], (half_t)sc[2 * c][3],
+                              (half_t)sc[2 * c + 1][0], (half_t)sc[2 * c + 1][1], (half_t)sc[2 * c + 1][2], (half_t)sc[2 * c + 1][3]};
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const half_t* kp = T0 + (nf * 16 + li) * VST + c * 32 + lg * 4;
+                const half4 k0 = *(const half4*)kp;
+                const half4 k1 = *(const half4*)(kp + 16);
+                const half8 kf = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+                dq[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, sf, dq[nf], 0, 0, 0);
+            }
+        }
+        if (qrow < S) {
+            half_t* op = dbase + qrow * ld + lg * 4;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const f32x4 v = dq[nf] * 0.125f;
+                *(half4*)(op + nf * 16) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            }
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ restage: T0 = (Q/8)^T, T1 = dO^T
+    for (int idx = tid; idx < SP * 8; idx += 256) {
+        const int row = idx >> 3, chunk = idx & 7;
+        half8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, dv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < S) {
+            qv = *(const half8*)(base + row * ld + chunk * 8);
+            qv *= (half_t)0.125f;
+            dv = *(const half8*)(dobase + (size_t)row * D + chunk * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T0[(chunk * 8 + j) * VST + row] = qv[j];
+            T1[(chunk * 8 + j) * VST + row] = dv[j];
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase 2: dK, dV per key tile
+    const int n_kt = (S + 15) >> 4;
+    for (int kt = wave; kt < n_kt; kt += 4) {
+        asm volatile("" ::: "memory");
+        const int kvrow = kt * 16 + li;   // this lane's key (B-operand row / output column)
+        half8 kf[2], vf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sw = ((kk * 4 + lg) ^ (lane & 7)) * 8;
+            kf[kk] = *(const half8*)(Ks + kvrow * 64 + sw);
+            vf[kk] = *(const half8*)(Vs + kvrow * 64 + sw);
+        }
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) { dk[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        const int c_begin = CAUSAL ? (kt * 16) / 32 : 0;   // queries before the key tile see none of its keys
+        for (int c = c_begin; c < KVC; ++c) {
+            half8 pf, sf;
+#pragma unroll
+            for (int half_i = 0; half_i < 2; ++half_i) {
+                const int q0 = c * 32 + half_i * 16;
+                // A operands: query rows straight from HBM (row = q0 + li)
+                const int qa = (q0 + li) < S ? (q0 + li) : S - 1;
+                f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    half8 qa_f = *(const half8*)(base + qa * ld + (kk * 4 + lg) * 8);
+                    qa_f *= (half_t)0.125f;
+                    const half8 do_f = *(const half8*)(dobase + (size_t)qa * D + (kk * 4 + lg) * 8);
+                    s_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa_f, kf[kk], s_acc, 0, 0, 0);   // S[q][kv]
+                    p_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(do_f, vf[kk], p_acc, 0, 0, 0);   // dP[q][kv]
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + lg * 4 + r;
+                    float p = 0.f, ds = 0.f;   // padding rows carry no statistics: keep them exactly zero
+                    if (q < S && kvrow < S && !(CAUSAL && kvrow > q)) {
+                        p = __expf(s_acc[r] - st_m[q]) * st_il[q];
+                        ds = p * (p_acc[r] - st_d[q]);
+                    }
+                    pf[half_i * 4 + r] = (half_t)p;
+                    sf[half_i * 4 + r] = (half_t)ds;
+                }
+            }
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const half_t* dp = T1 + (nf * 16 + li) * VST + c * 32 + lg * 4;
+                const half4 d0 = *(const half4*)dp;
+                const half4 d1 = *(const half4*)(dp + 16);
+                const half8 dof = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+                dv[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dof, pf, dv[nf], 0, 0, 0);   // dV^T[dh][kv]
+                const half_t* qp = T0 + (nf * 16 + li) * VST + c * 32 + lg * 4;
+                const half4 q0v = *(const half4*)qp;
+                const half4 q1v = *(const half4*)(qp + 16);
+                const half8 qtf = {q0v[0], q0v[1], q0v[2], q0v[3], q1v[0], q1v[1], q1v[2], q1v[3]};
+                dk[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, sf, dk[nf], 0, 0, 0);   // dK^T[dh][kv]
+            }
+        }
+        if (kvrow < S) {
+            half_t* kp = dbase + kvrow * ld + D + lg * 4;
+            half_t* vp = dbase + kvrow * ld + 2 * D + lg * 4;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                *(half4*)(kp + nf * 16) = (half4){(half_t)dk[nf][0], (half_t)dk[nf][1], (half_t)dk[nf][2], (half_t)dk[nf][3]};
+                *(half4*)(vp + nf * 16) = (half4){(half_t)dv[nf][0], (half_t)dv[nf][1], (half_t)dv[nf][2], (half_t)dv[nf][3]};
+            }
+        }
+    }
+}
+
+template <int KVC, bool CAUSAL>
+static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, hipStream_t s) {
+    constexpr int SP = KVC * 32;
+    constexpr size_t lds = (size_t)2 * SP * 64 * 2 + (size_t)2 * 64 * (SP + 8) * 2 + (size_t)3 * SP * 4;
+    static_assert(lds <= 160 * 1024, "attention backward tile does not fit LDS");
+    static bool configured = false;
+    if (!configured) {
+        GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel<KVC, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_kernel<KVC, CAUSAL>), dim3(B * H), dim3(256), lds, s, qkv, o, d_out, dqkv, S, H);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s) {
+    const int kvc = (S + 31) / 32;
+    GRIP_REQUIRE(S >= 1 && kvc <= 8, "attention backward: sequence length %d unsupported (max 256 in this round)", S);
+#define GRIP_ATTN(N)                                                                        \
+    if (kvc <= N) return causal ? launch_bwd_one<N, true>(qkv, o, d_out, dqkv, B, S, H, s)  \
+                                : launch_bwd_one<N, false>(qkv, o, d_out, dqkv, B, S, H, s);
+    GRIP_ATTN(1) GRIP_ATTN(2) GRIP_ATTN(3) GRIP_ATTN(7) GRIP_ATTN(8)
+#undef GRIP_ATTN
+    return GRIP_ERR_ARG;
+}

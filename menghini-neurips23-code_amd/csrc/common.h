@@ -77,3 +77,11 @@ int launch_transpose_f16(const half_t* in, half_t* out, int rows, int cols, int 
 
 // attention (attention.hip): qkv [B*S, 3*D] f16 -> out [B*S, D] f16
 int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s);
+int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
+// backward row kernels (rowops_bwd.hip)
+int launch_ln_bwd_add(const float* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s);
+int launch_ln_bwd_scatter(const float* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
+                          int n, int d, hipStream_t s);
+int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* gamma, const float* scale, float* grad, int B, int S, int P, int d, hipStream_t s);
+int launch_text_prefix_grad(const float* dx, const float* scale, float* grad, int C, int T, int P, int prefix_classes, int d, hipStream_t s);
+int launch_grad_scale_cast(const float* g, half_t* g16, float* scale, int n, hipStream_t s);

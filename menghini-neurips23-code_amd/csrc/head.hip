@@ -120,3 +120,102 @@ extern "C" int grip_cosine_head(const float* img_emb, const float* txt_emb, floa
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of logits = scale * ihat @ that^T (ihat, that = L2-normalised rows).
+//   d ihat = scale * dL @ that;  d img = (d ihat - ihat * <ihat, d ihat>) / ||img||      (same for txt with dL^T)
+// One wave per output row; `other` rows are normalised on the fly (n and c are small in training).
+__global__ __launch_bounds__(256) void cosine_head_bwd_kernel(const float* __restrict__ self, const float* __restrict__ other, float scale,
+                                                              int n_self, int n_other, int e, const float* __restrict__ dl, int transposed,
+                                                              int ld_dl, float* __restrict__ grad) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_self) return;
+    const int e4 = e >> 2;
+    f32x4 acc[HEAD_MAX_EV];
+#pragma unroll
+    for (int i = 0; i < HEAD_MAX_EV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < n_other; ++j) {
+        const f32x4* o = (const f32x4*)(other + (size_t)j * e);
+        f32x4 v[HEAD_MAX_EV];
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < HEAD_MAX_EV; ++i)
+            if (lane + 64 * i < e4) { v[i] = o[lane + 64 * i]; q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3]; }
+        const float inv = 1.0f / sqrtf(wsum(q));
+        const float g = scale * (transposed ? dl[(size_t)j * ld_dl + row] : dl[(size_t)row * ld_dl + j]) * inv;
+#pragma unroll
+        for (int i = 0; i < HEAD_MAX_EV; ++i)
+            if (lane + 64 * i < e4) acc[i] += v[i] * g;
+    }
+    const f32x4* x = (const f32x4*)(self + (size_t)row * e);
+    f32x4 xs[HEAD_MAX_EV];
+    float q = 0.f, dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEAD_MAX_EV; ++i)
+        if (lane + 64 * i < e4) {
+            xs[i] = x[lane + 64 * i];
+            q += xs[i][0] * xs[i][0] + xs[i][1] * xs[i][1] + xs[i][2] * xs[i][2] + xs[i][3] * xs[i][3];
+            dot += xs[i][0] * acc[i][0] + xs[i][1] * acc[i][1] + xs[i][2] * acc[i][2] + xs[i][3] * acc[i][3];
+        }
+    q = wsum(q);
+    dot = wsum(dot);
+    const float inv = 1.0f / sqrtf(q);
+    const float proj = dot / q;   // <xhat, d xhat> / ||x||  =  <x, d xhat> / ||x||^2
+    f32x4* o = (f32x4*)(grad + (size_t)row * e);
+#pragma unroll
+    for (int i = 0; i < HEAD_MAX_EV; ++i)
+        if (lane + 64 * i < e4) o[lane + 64 * i] = (acc[i] - xs[i] * proj) * inv;
+}
+
+extern "C" int grip_cosine_head_backward(const float* img_emb, const float* txt_emb, float scale, int n, int c, int e,
+                                         const float* grad_logits, float* grad_img, float* grad_txt, void* stream) {
+    GRIP_REQUIRE(img_emb && txt_emb && grad_logits, "cosine_head_backward: null pointer");
+    GRIP_REQUIRE(n > 0 && c > 0 && e % 4 == 0 && e <= 256 * HEAD_MAX_EV, "cosine_head_backward: unsupported shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_img)
+        hipLaunchKernelGGL(cosine_head_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, s, img_emb, txt_emb, scale, n, c, e, grad_logits, 0, c, grad_img);
+    if (grad_txt)
+        hipLaunchKernelGGL(cosine_head_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, s, txt_emb, img_emb, scale, c, n, e, grad_logits, 1, c, grad_txt);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss = sum_i w_i * (logsumexp(logits_i) - logits_i[label_i]);  grad_i = w_i * (softmax(logits_i) - onehot(label_i)).
+// One block, wave w walks rows w, w+4, ...; partial sums are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void weighted_ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                          const float* __restrict__ weight, int n, int c, float* __restrict__ loss,
+                                                          float* __restrict__ grad) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float total = 0.f;
+    for (int row = wave; row < n; row += 4) {
+        const float* x = logits + (size_t)row * c;
+        const float w = weight[row];
+        const int lab = labels[row];
+        float m = -INFINITY;
+        for (int j = lane; j < c; j += 64) m = fmaxf(m, x[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int j = lane; j < c; j += 64) sum += expf(x[j] - m);
+        sum = wsum(sum);
+        const float lse = m + logf(sum);
+        if (grad)
+            for (int j = lane; j < c; j += 64) grad[(size_t)row * c + j] = w * (expf(x[j] - m) / sum - (j == lab ? 1.f : 0.f));
+        if (w != 0.f && lab >= 0 && lab < c) total += w * (lse - x[lab]);
+    }
+    if (lane == 0) part[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
+extern "C" int grip_weighted_ce(const float* logits, const int32_t* labels, const float* row_weight, int n, int c,
+                                float* loss, float* grad_logits, void* stream) {
+    GRIP_REQUIRE(logits && labels && row_weight && loss, "weighted_ce: null pointer");
+    GRIP_REQUIRE(n > 0 && c > 0, "weighted_ce: empty input");
+    hipLaunchKernelGGL(weighted_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, row_weight, n, c, loss, grad_logits);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

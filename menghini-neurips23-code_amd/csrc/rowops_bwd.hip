@@ -1,0 +1,207 @@
+// Row-wise kernels of the backward (input-gradient) chain: LayerNorm backward fused with the
+// residual-gradient add and the f16 re-quantisation for the next GEMM, the CLS/EOT scatter through
+// ln_post / ln_final, the prompt-slice reductions, and the dynamic loss scale.
+// Same one-wave-per-row, float4-per-lane structure as rowops.hip.
+#include <math.h>
+
+#include "common.h"
+
+#define LN_EPS 1e-5f
+
+__device__ __forceinline__ float wave_sum_b(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
+template <int NV>
+__device__ __forceinline__ void ln_bwd_row(const f32x4* __restrict__ xr, const f32x4* __restrict__ dyr, const f32x4* __restrict__ gamma,
+                                           int lane, int d4, int d, f32x4 (&dx)[NV]) {
+    f32x4 x[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) { x[i] = xr[lane + 64 * i]; s += x[i][0] + x[i][1] + x[i][2] + x[i][3]; }
+    const float mean = wave_sum_b(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) { x[i] = x[i] - mean; q += x[i][0] * x[i][0] + x[i][1] * x[i][1] + x[i][2] * x[i][2] + x[i][3] * x[i][3]; }
+    const float rstd = rsqrtf(wave_sum_b(q) / (float)d + LN_EPS);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            x[i] = x[i] * rstd;                                    // xhat
+            dx[i] = dyr[lane + 64 * i] * gamma[lane + 64 * i];     // g
+            a += dx[i][0] + dx[i][1] + dx[i][2] + dx[i][3];
+            b += dx[i][0] * x[i][0] + dx[i][1] * x[i][1] + dx[i][2] * x[i][2] + dx[i][3] * x[i][3];
+        }
+    a = wave_sum_b(a) / (float)d;
+    b = wave_sum_b(b) / (float)d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) dx[i] = (dx[i] - a - x[i] * b) * rstd;
+}
+
+// dx[r] += LNbwd(dln[r]; x[r]);  dxh[r] = f16(dx[r])            (r < M)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dln, const float* __restrict__ gamma,
+                                                         float* __restrict__ dx, half_t* __restrict__ dxh, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int d4 = d >> 2;
+    f32x4 g[NV];
+    ln_bwd_row<NV>((const f32x4*)(x + (size_t)row * d), (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g);
+    f32x4* o = (f32x4*)(dx + (size_t)row * d);
+    half4* oh = (half4*)(dxh + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            const f32x4 v = o[lane + 64 * i] + g[i];
+            o[lane + 64 * i] = v;
+            oh[lane + 64 * i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+}
+
+// Final LayerNorm (ln_post on the CLS row / ln_final on the EOT row): dx[row_b] = LNbwd(dy[b]; x[row_b]),
+// row_b = b * stride + (index ? index[b] : 0).  dx / dxh were zero-filled before.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_scatter_kernel(const float* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ index,
+                                                             int stride, const float* __restrict__ gamma, float* __restrict__ dx,
+                                                             half_t* __restrict__ dxh, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int d4 = d >> 2;
+    const size_t row = (size_t)b * stride + (index ? index[b] : 0);
+    f32x4 g[NV];
+    ln_bwd_row<NV>((const f32x4*)(x + row * d), (const f32x4*)(dy + (size_t)b * d), (const f32x4*)gamma, lane, d4, d, g);
+    f32x4* o = (f32x4*)(dx + row * d);
+    half4* oh = (half4*)(dxh + row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            o[lane + 64 * i] = g[i];
+            oh[lane + 64 * i] = (half4){(half_t)g[i][0], (half_t)g[i][1], (half_t)g[i][2], (half_t)g[i][3]};
+        }
+}
+
+// Visual prompt slice through ln_pre: grad_prefix[s] = inv_scale * sum_b LNbwd(dx[b*S + 1 + s]; prefix[s]).
+// One wave per prompt token, fixed summation order over the batch (deterministic).
+template <int NV>
+__global__ __launch_bounds__(256) void vit_prefix_grad_kernel(const float* __restrict__ dx, const float* __restrict__ prefix, const float* __restrict__ gamma,
+                                                              const float* __restrict__ scale, float* __restrict__ grad, int B, int S, int P, int d) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= P) return;
+    const int d4 = d >> 2;
+    f32x4 acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        f32x4 g[NV];
+        ln_bwd_row<NV>((const f32x4*)(prefix + (size_t)s * d), (const f32x4*)(dx + ((size_t)b * S + 1 + s) * d), (const f32x4*)gamma, lane, d4, d, g);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < d4) acc[i] += g[i];
+    }
+    const float inv = scale[1];
+    f32x4* o = (f32x4*)(grad + (size_t)s * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) o[lane + 64 * i] = acc[i] * inv;
+}
+
+// Textual prompt slice: grad_prefix[pc][p] = inv_scale * sum_{c in group} dx[c*T + 1 + p]
+__global__ __launch_bounds__(256) void text_prefix_grad_kernel(const float* __restrict__ dx, const float* __restrict__ scale, float* __restrict__ grad,
+                                                               int C, int T, int P, int prefix_classes, int d) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= prefix_classes * P) return;
+    const int pc = idx / P, p = idx - pc * P;
+    const int d4 = d >> 2;
+    const float inv = scale[1];
+    for (int f = lane; f < d4; f += 64) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (prefix_classes == 1) {
+            for (int c = 0; c < C; ++c) acc += ((const f32x4*)(dx + ((size_t)c * T + 1 + p) * d))[f];
+        } else {
+            acc = ((const f32x4*)(dx + ((size_t)pc * T + 1 + p) * d))[f];
+        }
+        ((f32x4*)(grad + (size_t)idx * d))[f] = acc * inv;
+    }
+}
+
+// Dynamic loss scale: scale[0] = 2^k with amax(g) * 2^k in [32, 64), scale[1] = 2^-k; g16 = f16(g * scale).
+// Keeps the f16 gradient operands of the dgrad GEMMs away from the subnormal range; the chain is
+// linear in g, so the power-of-two scale is exact and is divided out at the prompt slice.
+__global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __restrict__ g, half_t* __restrict__ g16, float* __restrict__ scale, int n) {
+    __shared__ float red[16];
+    __shared__ float sc;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int i = 0; i < 16; ++i) a = fmaxf(a, red[i]);
+        int e = 0;
+        if (a > 0.f && isfinite(a)) {
+            frexpf(a, &e);         // a = f * 2^e, f in [0.5, 1)
+            e = 6 - e;             // a * 2^e in [32, 64)
+            e = e > 40 ? 40 : (e < -40 ? -40 : e);
+        }
+        sc = ldexpf(1.0f, e);
+        scale[0] = sc;
+        scale[1] = ldexpf(1.0f, -e);
+    }
+    __syncthreads();
+    const float s = sc;
+    for (int i = threadIdx.x; i < n; i += 1024) g16[i] = (half_t)(g[i] * s);
+}
+
+#define DISPATCH_NV_B(d, CALL)                                                                 \
+    do {                                                                                       \
+        const int _nv = ((d) / 4 + 63) / 64;                                                   \
+        GRIP_REQUIRE((d) % 4 == 0 && _nv >= 1 && _nv <= 8, "row kernel: unsupported width %d", (d)); \
+        switch (_nv) {                                                                         \
+            case 1: { constexpr int NV = 1; CALL; } break;                                     \
+            case 2: { constexpr int NV = 2; CALL; } break;                                     \
+            case 3: { constexpr int NV = 3; CALL; } break;                                     \
+            case 4: { constexpr int NV = 4; CALL; } break;                                     \
+            case 5: case 6: { constexpr int NV = 6; CALL; } break;                             \
+            default: { constexpr int NV = 8; CALL; } break;                                    \
+        }                                                                                      \
+    } while (0)
+
+int launch_ln_bwd_add(const float* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s) {
+    DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_add_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, dx, dxh, M, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+int launch_ln_bwd_scatter(const float* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
+                          int n, int d, hipStream_t s) {
+    DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_scatter_kernel<NV>, dim3((n + 3) / 4), dim3(256), 0, s, x, dy, index, stride, gamma, dx, dxh, n, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* gamma, const float* scale, float* grad, int B, int S, int P, int d, hipStream_t s) {
+    DISPATCH_NV_B(d, hipLaunchKernelGGL(vit_prefix_grad_kernel<NV>, dim3((P + 3) / 4), dim3(256), 0, s, dx, prefix, gamma, scale, grad, B, S, P, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+int launch_text_prefix_grad(const float* dx, const float* scale, float* grad, int C, int T, int P, int prefix_classes, int d, hipStream_t s) {
+    hipLaunchKernelGGL(text_prefix_grad_kernel, dim3((prefix_classes * P + 3) / 4), dim3(256), 0, s, dx, scale, grad, C, T, P, prefix_classes, d);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+int launch_grad_scale_cast(const float* g, half_t* g16, float* scale, int n, hipStream_t s) {
+    hipLaunchKernelGGL(grad_scale_cast_kernel, dim3(1), dim3(1024), 0, s, g, g16, scale, n);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

@@ -394,3 +394,90 @@ extern "C" int grip_debug_attention(const void* qkv, void* out, int B, int S, in
 extern "C" int grip_debug_layernorm(const float* x, const float* gamma, const float* beta, void* out, int M, int d, void* stream) {
     return launch_layernorm_f16(x, gamma, beta, (half_t*)out, M, d, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------- backward
+// Input-gradient chain of one tower down to its prompt slice.  Enters with dx / dxh holding the
+// (loss-scaled) gradient w.r.t. the final residual stream, leaves with dx = gradient w.r.t. x0.
+static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, hipStream_t s) {
+    const int d = t->D.width, H = t->D.heads;
+    const half_t* W = t->w16;
+    const float* F = t->w32;
+    for (int l = t->D.layers - 1; l >= 0; --l) {
+        const LayerW& lw = t->L.layer[(size_t)l];
+        GemmArgs a{};
+        // d(pre-activation) = (dx @ W_proj) * quickgelu'(h_pre)
+        a.A = w.dxh; a.W = W + lw.proj_wT; a.M = w.M; a.N = 4 * d; a.K = d; a.aux = w.hpre_l[(size_t)l]; a.out = w.dh; a.ldc = 4 * d;
+        RUN(launch_gemm(EPI_GELUGRAD_F16, a, s));
+        a = GemmArgs{};
+        a.A = w.dh; a.W = W + lw.fc_wT; a.M = w.M; a.N = d; a.K = 4 * d; a.out = w.dln; a.ldc = d;
+        RUN(launch_gemm(EPI_F32, a, s));
+        RUN(launch_ln_bwd_add(w.x_mid[(size_t)l], w.dln, F + lw.ln2_g, w.dx, w.dxh, w.M, d, s));
+        a = GemmArgs{};
+        a.A = w.dxh; a.W = W + lw.out_wT; a.M = w.M; a.N = d; a.K = d; a.out = w.datt; a.ldc = d;
+        RUN(launch_gemm(EPI_F16, a, s));
+        RUN(launch_attention_bwd(w.qkv_l[(size_t)l], w.att_l[(size_t)l], w.datt, w.dqkv, w.batch, w.S, H, causal, s));
+        a = GemmArgs{};
+        a.A = w.dqkv; a.W = W + lw.in_wT; a.M = w.M; a.N = d; a.K = 3 * d; a.out = w.dln; a.ldc = d;
+        RUN(launch_gemm(EPI_F32, a, s));
+        RUN(launch_ln_bwd_add(w.x_in[(size_t)l], w.dln, F + lw.ln1_g, w.dx, w.dxh, w.M, d, s));
+    }
+    return GRIP_OK;
+}
+
+static int backward_head_of_tower(grip_tower* t, Workspace& w, const float* grad_emb, const int32_t* index, hipStream_t s) {
+    const grip_dims& D = t->D;
+    const int d = D.width;
+    // scale + f16 cast of dL/d(emb); d(ln output) = g @ proj^T  (W = proj [d, E] as stored: N = d, K = E)
+    RUN(launch_grad_scale_cast(grad_emb, w.gemb16, w.scale, w.batch * D.embed_dim, s));
+    GemmArgs a{};
+    a.A = w.gemb16; a.W = t->w16 + t->L.proj; a.M = w.batch; a.N = d; a.K = D.embed_dim; a.out = w.dcls; a.ldc = d;
+    RUN(launch_gemm(EPI_F32, a, s));
+    GRIP_CHECK_HIP(hipMemsetAsync(w.dx, 0, (size_t)w.M * d * 4, s));
+    GRIP_CHECK_HIP(hipMemsetAsync(w.dxh, 0, (size_t)w.M * d * 2, s));
+    RUN(launch_ln_bwd_scatter(w.x_in[(size_t)D.layers], w.dcls, index, w.S, t->w32 + t->L.lnpost_g, w.dx, w.dxh, w.batch, d, s));
+    return GRIP_OK;
+}
+
+static int check_bwd(grip_tower* t, void* workspace, size_t workspace_bytes) {
+    GRIP_REQUIRE(t && workspace, "backward: null pointer");
+    if (t->last_ws != workspace || !t->last.train) {
+        grip_set_error("backward without a matching train-mode forward on this workspace");
+        return GRIP_ERR_STATE;
+    }
+    if (t->last.bytes > workspace_bytes) { grip_set_error("backward: workspace too small"); return GRIP_ERR_WORKSPACE; }
+    return GRIP_OK;
+}
+
+extern "C" int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* prefix, float* grad_prefix,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    try {
+        GRIP_REQUIRE(t && t->D.kind == 0 && grad_emb && prefix && grad_prefix, "vit_backward_prefix: bad arguments");
+        RUN(check_bwd(t, workspace, workspace_bytes));
+        Workspace& w = t->last;
+        GRIP_REQUIRE(w.P > 0, "vit_backward_prefix: forward had no prompt tokens");
+        hipStream_t s = (hipStream_t)stream;
+        RUN(backward_head_of_tower(t, w, grad_emb, nullptr, s));
+        RUN(run_blocks_backward(t, w, 0, s));
+        RUN(launch_vit_prefix_grad(w.dx, prefix, t->w32 + t->L.lnpre_g, w.scale, grad_prefix, w.batch, w.S, w.P, t->D.width, s));
+        return GRIP_OK;
+    } catch (...) { grip_set_error("vit_backward_prefix: exception"); return GRIP_ERR_ARG; }
+}
+
+extern "C" int grip_text_backward_prefix(grip_tower* t, const float* grad_emb, float* grad_prefix,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    try {
+        GRIP_REQUIRE(t && t->D.kind == 1 && grad_emb && grad_prefix, "text_backward_prefix: bad arguments");
+        RUN(check_bwd(t, workspace, workspace_bytes));
+        Workspace& w = t->last;
+        GRIP_REQUIRE(w.P > 0, "text_backward_prefix: forward had no prompt tokens");
+        hipStream_t s = (hipStream_t)stream;
+        RUN(backward_head_of_tower(t, w, grad_emb, t->last_eot, s));
+        RUN(run_blocks_backward(t, w, 1, s));
+        RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, w.batch, t->D.seq0, w.P, t->last_prefix_classes, t->D.width, s));
+        return GRIP_OK;
+    } catch (...) { grip_set_error("text_backward_prefix: exception"); return GRIP_ERR_ARG; }
+}
+
+extern "C" int grip_debug_attention_bwd(const void* qkv, const void* o, const void* d_out, void* dqkv, int B, int S, int H, int causal, void* stream) {
+    return launch_attention_bwd((const half_t*)qkv, (const half_t*)o, (const half_t*)d_out, (half_t*)dqkv, B, S, H, causal, (hipStream_t)stream);
+}

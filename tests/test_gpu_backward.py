@@ -1,0 +1,179 @@
+"""Backward (input-gradient) parity on the GPU: kernel level against torch autograd in fp32, tower
+level against the committed golden gradients (autograd through the reference's own wrappers over
+the CPU oracle, oracle/gen_golden.py).  Tolerance for prompt gradients: cosine >= 0.999 and
+relative L2 error <= 3e-2 (f16 gradient operands with a dynamic power-of-two loss scale)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SEED = 100
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _inputs(name, shape, std=1.0):
+    import grip_amd  # noqa: F401
+    from grip_amd import rng
+    return torch.from_numpy(rng.normal(SEED, rng.stream_id(name), shape, 0.0, std))
+
+
+def assert_grad_close(got, want, what, cos_tol=1e-3, rel_tol=3e-2):
+    got = got.detach().float().cpu().reshape(-1)
+    want = torch.as_tensor(np.asarray(want)).float().reshape(-1)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite gradient"
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=0).item()
+    rel = ((got - want).norm() / want.norm()).item()
+    assert 1 - cos <= cos_tol, f"{what}: 1-cos = {1 - cos:.3e} (rel {rel:.3e})"
+    assert rel <= rel_tol, f"{what}: relative L2 error {rel:.3e}"
+
+
+@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (2, 40, 2, 1), (2, 77, 8, 1), (2, 197, 12, 0), (1, 213, 12, 0), (1, 250, 3, 0)])
+def test_attention_backward(B, S, H, causal):
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    lib = native.lib()
+    g = torch.Generator(device="cuda").manual_seed(S + 1)
+    D = H * 64
+    qkv = (torch.randn(B * S, 3 * D, device="cuda", generator=g)).half()
+    dout = (torch.randn(B * S, D, device="cuda", generator=g)).half()
+    out = torch.zeros(B * S, D, device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_attention(_p(qkv), _p(out), B, S, H, causal, _stream()))
+    dqkv = torch.full((B * S, 3 * D), float("nan"), device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_attention_bwd(_p(qkv), _p(out), _p(dout), _p(dqkv), B, S, H, causal, _stream()))
+
+    x = qkv.float().clone().requires_grad_(True)
+    q, k, v = x.reshape(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((S, S), float("-inf"), device="cuda").triu(1)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    ref.backward(dout.float())
+    want = x.grad.reshape(B * S, 3, D)
+    got = dqkv.float().reshape(B * S, 3, D)
+    for i, nm in enumerate("qkv"):
+        assert_grad_close(got[:, i], want[:, i].cpu(), f"d{nm}", cos_tol=1e-4, rel_tol=1e-2)
+
+
+def test_cosine_head_and_ce_backward():
+    import grip_amd  # noqa: F401
+    from grip_amd.engine import CosineHeadFn, WeightedCEFn
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.randn(16, 512, device="cuda", generator=g, requires_grad=True)
+    txt = torch.randn(47, 512, device="cuda", generator=g, requires_grad=True)
+    labels = torch.randint(0, 47, (16,), device="cuda", generator=g)
+    w = torch.rand(16, device="cuda", generator=g)
+    w[3] = 0.0
+    loss = WeightedCEFn.apply(CosineHeadFn.apply(img, txt, 100.0), labels, w)
+    loss.backward()
+    gi, gt = img.grad.clone(), txt.grad.clone()
+    img.grad = txt.grad = None
+    i = img / img.norm(dim=-1, keepdim=True)
+    t = txt / txt.norm(dim=-1, keepdim=True)
+    ref = (torch.nn.functional.cross_entropy(100.0 * i @ t.t(), labels, reduction="none") * w).sum()
+    ref.backward()
+    torch.testing.assert_close(loss, ref, rtol=1e-4, atol=1e-4)
+    assert_grad_close(gi, img.grad.cpu(), "d img", cos_tol=1e-5, rel_tol=1e-3)
+    assert_grad_close(gt, txt.grad.cpu(), "d txt", cos_tol=1e-5, rel_tol=1e-3)
+
+
+@pytest.fixture(scope="module")
+def models():
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = clip.load(name, device="cuda")[0]
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("tag,name,n_img,P", [("g1", "tiny", 3, 3), ("g1s", "small", 2, 16)])
+def test_golden_prompt_gradients(models, golden_small, tag, name, n_img, P):
+    """grad of sum(out^2) w.r.t. the visual / textual prompt, as the reference wrappers produce it."""
+    import grip_amd  # noqa: F401
+    from grip_amd import config
+    from grip_amd.models import CustomImageEncoder, CustomTextEncoder, ImagePrefixModel
+    m = models(name)
+    d = config.get_dims(name)
+    x = _inputs(f"{tag}.x", (n_img, 3, d.image_resolution, d.image_resolution)).cuda()
+    vprefix = _inputs(f"{tag}.vprefix", (P, d.vision_width), 0.02).cuda()
+    model = ImagePrefixModel(vprefix.clone(), CustomImageEncoder(m.visual), device="cuda")
+    out = model(x)
+    (out ** 2).sum().backward()
+    assert_grad_close(model.prefix.grad, golden_small[f"{tag}.vision_p{P}_grad_prefix"], "visual prompt grad")
+    for prm in m.parameters():
+        assert prm.grad is None and not prm.requires_grad      # frozen backbone
+
+    tprefix = _inputs(f"{tag}.tprefix", (1, P, d.transformer_width), 0.02).cuda().requires_grad_(True)
+    from grip_amd.engine import TextPrefixFn
+    ctok = torch.from_numpy(golden_small[f"{tag}.coop_tokens"]).cuda()
+    tout = TextPrefixFn.apply(m.text_tower, ctok, tprefix)
+    (tout ** 2).sum().backward()
+    assert_grad_close(tprefix.grad, golden_small[f"{tag}.text_p{P}_grad_prefix"], "textual prompt grad")
+
+
+def test_golden_upt_end_to_end(models, golden_small):
+    """G4: UPTModel forward (mixer with the f16 round trip, both towers), CE loss, all gradients."""
+    import grip_amd  # noqa: F401
+    from grip_amd import config, weights
+    from grip_amd.engine import CosineHeadFn, WeightedCEFn
+    from grip_amd.models import CustomImageEncoder, CustomTextEncoder, UPTModel
+    g = golden_small
+    m = models("tiny")
+    d = config.get_dims("tiny")
+    classes = ["forest", "annual crop land", "river"]
+    x = _inputs("g4.x", (3, 3, d.image_resolution, d.image_resolution)).cuda()
+    coop = _inputs("g4.coop", (1, 4, d.transformer_width), 0.02).cuda()
+    vpt = _inputs("g4.vpt", (1, 4, d.vision_width), 0.02).cuda()
+    upt = UPTModel(coop, vpt, None, CustomImageEncoder(m.visual), CustomTextEncoder(m, "cuda", torch.float32), classes, 128,
+                   device="cuda", dtype=torch.float32)
+    mixer = {k: torch.from_numpy(v) for k, v in weights.init_upt_mixer(d.transformer_width, d.vision_width, 128, SEED).items()}
+    missing, unexpected = upt.load_state_dict(mixer, strict=False)
+    assert not unexpected
+    ce, ve = upt.mix()
+    torch.testing.assert_close(ce.cpu(), torch.from_numpy(g["g4.mixer_coop"]), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(ve.cpu(), torch.from_numpy(g["g4.mixer_vpt"]), rtol=2e-3, atol=2e-3)
+    t_out, v_out = upt(x, classes)
+    from test_gpu_towers import assert_embeddings_close
+    assert_embeddings_close(t_out, g["g4.text"], "upt text")
+    assert_embeddings_close(v_out, g["g4.vision"], "upt vision")
+    logits = CosineHeadFn.apply(v_out, t_out, m.logit_scale.exp().item())
+    labels = torch.arange(3, device="cuda") % 3
+    loss = WeightedCEFn.apply(logits, labels, torch.full((3,), 1 / 3, device="cuda"))
+    assert abs(loss.item() - float(g["g4.loss"])) <= 2e-2 * max(1.0, abs(float(g["g4.loss"])))
+    loss.backward()
+    for name, p in upt.named_parameters():
+        key = f"g4.grad.{name}"
+        if key in g.files:
+            assert p.grad is not None, name
+            assert_grad_close(p.grad, g[key], name, cos_tol=5e-3, rel_tol=8e-2)
+
+
+def test_vitb16_gradient_vs_oracle(models):
+    """Full-size VPT step shape (B=4, P=16) against CPU-oracle autograd computed here."""
+    from conftest import oracle_clip
+    from oracle import wrappers as W
+    import grip_amd  # noqa: F401
+    from grip_amd.engine import VitPrefixFn
+    om, _ = oracle_clip().load("ViT-B/16")
+    m = models("ViT-B/16")
+    x = _inputs("b16g.x", (4, 3, 224, 224))
+    prefix = _inputs("b16g.p", (16, 768), 0.02)
+    w = _inputs("b16g.w", (4, 512))
+    pc = prefix.clone().requires_grad_(True)
+    (W.vision_forward(om.visual, x, pc) * w).sum().backward()
+    pg = prefix.clone().cuda().requires_grad_(True)
+    (VitPrefixFn.apply(m.visual.tower, x.cuda(), pg) * w.cuda()).sum().backward()
+    assert_grad_close(pg.grad, pc.grad, "ViT-B/16 visual prompt grad")
