@@ -170,7 +170,7 @@ class VitPrefixFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tower, images, prefix):
-        need = prefix.requires_grad and torch.is_grad_enabled()
+        need = ctx.needs_input_grad[2]   # grad mode is off inside Function.forward
         out, ws = tower.vit_forward(images, prefix.detach(), train=need)
         ctx.tower, ctx.ws = tower, ws
         ctx.save_for_backward(prefix.detach())
@@ -189,9 +189,10 @@ class TextPrefixFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tower, token_ids, prefix):
-        need = prefix.requires_grad and torch.is_grad_enabled()
-        out, ws, _ = tower.text_forward(token_ids, prefix.detach(), train=need)
+        need = ctx.needs_input_grad[2]
+        out, ws, keep = tower.text_forward(token_ids, prefix.detach(), train=need)
         ctx.tower, ctx.ws = tower, ws
+        ctx.keep = keep   # the native handle remembers the EOT-index pointer until backward
         ctx.pshape, ctx.pdtype = prefix.shape, prefix.dtype
         return out
 
