@@ -147,7 +147,60 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
     }
 }
 
+// ---- optional in-library timing of the GEMM launches (HIP events on the launch stream), used by
+// bench.py for the live roofline figure.  Off by default; at most PROF_MAX launches are recorded.
+#include <vector>
+namespace {
+constexpr int PROF_MAX = 8192;
+struct ProfRec { int epi; double flops; hipEvent_t a, b; };
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t prof_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+extern "C" int grip_profile_enable(int on) {
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    g_prof = on != 0;
+    return GRIP_OK;
+}
+
+// Per epilogue id e in [0, n): launches[e], total milliseconds, total algorithmic FLOPs (2*M*N*K).
+// Synchronises the recorded events; call after the timed region.
+extern "C" int grip_profile_collect(int n, int64_t* launches, double* total_ms, double* total_flops) {
+    for (int i = 0; i < n; ++i) { launches[i] = 0; total_ms[i] = 0.0; total_flops[i] = 0.0; }
+    for (auto& r : g_recs) {
+        if (r.epi < 0 || r.epi >= n) continue;
+        GRIP_CHECK_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        GRIP_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        launches[r.epi] += 1;
+        total_ms[r.epi] += ms;
+        total_flops[r.epi] += r.flops;
+    }
+    return GRIP_OK;
+}
+
+static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s);
+
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
+    if (!g_prof || (int)g_recs.size() >= PROF_MAX) return launch_gemm_impl(epi, a, s);
+    ProfRec r{epi, 2.0 * a.M * (double)a.N * a.K, prof_event(), prof_event()};
+    if (!r.a || !r.b) return launch_gemm_impl(epi, a, s);
+    (void)hipEventRecord(r.a, s);
+    const int rc = launch_gemm_impl(epi, a, s);
+    (void)hipEventRecord(r.b, s);
+    g_recs.push_back(r);
+    return rc;
+}
+
+static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s) {
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;

@@ -1,0 +1,80 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm)
+on the xGMI mesh; "gloo" on CPU for the world_size-2 tests.
+
+The pseudolabel pool shards contiguously over ranks (rank r owns images [r*ceil(N/g), (r+1)*ceil(N/g)))
+so that the gathered embeddings are in dataset order; the only data-path collective is one
+all-gather of the [N/g, E] f32 embeddings.  Prompt gradients (<= 2.1 MB) are
+all-reduced once per step.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
+
+
+def init_from_env(backend=None):
+    """Initialise from torchrun's RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* when present."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or is_dist():
+        return world()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend)
+    return world()
+
+
+def shard_range(n, rank=None, world_size=None):
+    """Contiguous shard [lo, hi) of an ordered pool of n units, equal padded length `per`."""
+    if rank is None:
+        rank, world_size = world()
+    per = (n + world_size - 1) // world_size
+    lo = min(rank * per, n)
+    hi = min(lo + per, n)
+    return lo, hi, per
+
+
+def allgather_rows(local, n_total, per):
+    """local [<= per, E] rows of this rank's shard -> [n_total, E] in global order on every rank.
+    Pads the last shard to `per` rows and drops the padding after the gather."""
+    rank, ws = world()
+    if ws == 1:
+        return local[:n_total]
+    e = local.shape[1]
+    if local.shape[0] != per:
+        pad = torch.zeros(per, e, dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        local = pad
+    out = torch.empty(ws * per, e, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out[:n_total]
+
+
+def allreduce_mean_(tensors):
+    """In-place mean all-reduce of the (tiny) prompt gradients, flattened into one message."""
+    rank, ws = world()
+    if ws == 1 or not tensors:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat)
+    flat /= ws
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off: off + t.numel()].view_as(t))
+        off += t.numel()
+
+
+def barrier():
+    if is_dist():
+        dist.barrier()

@@ -1,0 +1,63 @@
+"""`pseudolabel_top_k` / `compute_pseudo_labels` with the reference's signatures
+(utils/clip_pseudolabels.py:13-156), cache file name and pickle schema, on the native engine."""
+import logging
+import os
+import pickle
+
+import torch
+
+from .. import clip
+from .. import pseudolabels as pl
+
+log = logging.getLogger(__name__)
+
+
+def _pool_images(dataset, transform, device):
+    """Images of `dataset.filepaths` in order.  A dataset may carry a pre-decoded tensor pool as
+    `dataset.images` ([N,3,R,R], aligned with filepaths); otherwise files are opened with PIL and
+    `transform` is applied per image (host I/O, as the reference does; batched on the device after)."""
+    images = getattr(dataset, "images", None)
+    if images is not None:
+        return images
+    from PIL import Image
+
+    class _Lazy:
+        n = len(dataset.filepaths)
+
+        def __call__(self, lo, hi):
+            return torch.stack([transform(Image.open(p).convert("RGB")) for p in dataset.filepaths[lo:hi]])
+    return _Lazy()
+
+
+def compute_pseudo_labels(k, template, dataset, classnames, transform, clip_model, label_to_idx, device, filename,
+                          chunk=256):
+    prompts = [f"{template}{' '.join(i.split('_'))}" for i in classnames]     # reference :24 (literal "{}" kept)
+    text = clip.tokenize(prompts).to(device)
+    with torch.no_grad():
+        txt = clip_model.encode_text(text)                                     # once, not once per image
+        emb = pl.encode_pool(clip_model.visual.tower, _pool_images(dataset, transform, device), chunk=chunk)
+    class_labels = [label_to_idx[c] for c in classnames]
+    log.info(f"Compute {k} pseudo-labeles")
+    new_imgs, new_labels = pl.pseudolabel_from_features(emb, txt, clip_model.logit_scale.exp().item(), list(dataset.filepaths),
+                                                        class_labels, k, argmax_on="probs")
+    dataset.filepaths = new_imgs
+    dataset.labels = new_labels
+    if getattr(dataset, "images", None) is not None:
+        dataset.images = None   # the pool tensor no longer lines up with the rebuilt lists
+    os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
+    with open(filename, "wb") as f:
+        pickle.dump({"filepaths": new_imgs, "labels": new_labels}, f)
+    return dataset
+
+
+def pseudolabel_top_k(config, data_name, k, template, dataset, classnames, transform, clip_model, label_to_idx, device,
+                      vis_encoder, split_seed):
+    filename = f"pseudolabels/{data_name}_{vis_encoder.replace('/', '')}_{config.LEARNING_PARADIGM}_{config.MODEL}_{k}_pseudolabels_split_{split_seed}.pickle"
+    if os.path.exists(filename):
+        with open(filename, "rb") as f:
+            pseudolabels = pickle.load(f)
+        dataset.filepaths = pseudolabels["filepaths"]
+        dataset.labels = pseudolabels["labels"]
+    else:
+        dataset = compute_pseudo_labels(k, template, dataset, classnames, transform, clip_model, label_to_idx, device, filename)
+    return dataset
