@@ -147,42 +147,56 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
     }
 }
 
-// ---- optional in-library timing of the GEMM launches (HIP events on the launch stream), used by
-// bench.py for the live roofline figure.  Off by default; at most PROF_MAX launches are recorded.
+// ---- optional in-library timing of EVERY GEMM launch (HIP events on the launch stream), used by
+// bench.py for the live roofline figure.  Off by default.  Records sit in a bounded ring; when it is
+// full the oldest half (long finished) is folded into per-epilogue accumulators.
+#include <deque>
 #include <vector>
 namespace {
-constexpr int PROF_MAX = 8192;
+constexpr int PROF_RING = 4096, PROF_EPIS = 8;
 struct ProfRec { int epi; double flops; hipEvent_t a, b; };
 bool g_prof = false;
-std::vector<ProfRec> g_recs;
+std::deque<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
+int64_t g_launches[PROF_EPIS];
+double g_ms[PROF_EPIS], g_flops[PROF_EPIS];
 hipEvent_t prof_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+void prof_drain(size_t keep) {
+    while (g_recs.size() > keep) {
+        ProfRec r = g_recs.front();
+        g_recs.pop_front();
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.epi >= 0 && r.epi < PROF_EPIS) {
+            g_launches[r.epi] += 1;
+            g_ms[r.epi] += ms;
+            g_flops[r.epi] += r.flops;
+        }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+}
 }  // namespace
 
 extern "C" int grip_profile_enable(int on) {
-    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
-    g_recs.clear();
+    prof_drain(0);
+    for (int i = 0; i < PROF_EPIS; ++i) { g_launches[i] = 0; g_ms[i] = 0.0; g_flops[i] = 0.0; }
     g_prof = on != 0;
     return GRIP_OK;
 }
 
-// Per epilogue id e in [0, n): launches[e], total milliseconds, total algorithmic FLOPs (2*M*N*K).
-// Synchronises the recorded events; call after the timed region.
+// Per epilogue id e in [0, n): launches[e], total milliseconds, total algorithmic FLOPs (2*M*N*K) of
+// every GEMM launched since grip_profile_enable(1).  Synchronises the outstanding events.
 extern "C" int grip_profile_collect(int n, int64_t* launches, double* total_ms, double* total_flops) {
-    for (int i = 0; i < n; ++i) { launches[i] = 0; total_ms[i] = 0.0; total_flops[i] = 0.0; }
-    for (auto& r : g_recs) {
-        if (r.epi < 0 || r.epi >= n) continue;
-        GRIP_CHECK_HIP(hipEventSynchronize(r.b));
-        float ms = 0.f;
-        GRIP_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-        launches[r.epi] += 1;
-        total_ms[r.epi] += ms;
-        total_flops[r.epi] += r.flops;
+    prof_drain(0);
+    for (int i = 0; i < n; ++i) {
+        launches[i] = i < PROF_EPIS ? g_launches[i] : 0;
+        total_ms[i] = i < PROF_EPIS ? g_ms[i] : 0.0;
+        total_flops[i] = i < PROF_EPIS ? g_flops[i] : 0.0;
     }
     return GRIP_OK;
 }
@@ -190,7 +204,8 @@ extern "C" int grip_profile_collect(int n, int64_t* launches, double* total_ms, 
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s);
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
-    if (!g_prof || (int)g_recs.size() >= PROF_MAX) return launch_gemm_impl(epi, a, s);
+    if (!g_prof) return launch_gemm_impl(epi, a, s);
+    if ((int)g_recs.size() >= PROF_RING) prof_drain(PROF_RING / 2);
     ProfRec r{epi, 2.0 * a.M * (double)a.N * a.K, prof_event(), prof_event()};
     if (!r.a || !r.b) return launch_gemm_impl(epi, a, s);
     (void)hipEventRecord(r.a, s);

@@ -67,6 +67,7 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C menghini-neurips23-code_amd/csrc`). "
                 "There is no CPU fallback.")
+        import torch  # noqa: F401  -- load torch's bundled HIP runtime first so both share one libamdhip64
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in {**_SIGS, **_DEBUG_SIGS}.items():
             fn = getattr(l, name)  # AttributeError if a declared symbol is not exported

@@ -1,0 +1,127 @@
+"""CPU: host-side logic of the product -- tokenizer stand-in, prompt strings, sharding, FPL row
+weights, the exact host leaderboard (C++ in libgrip_amd.so) against the oracles and the golden
+vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, oracle_clip
+
+
+def test_tokenizer_stand_in_is_identical_on_both_sides():
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    texts = ["a photo of a {}forest", "X X X X annual crop land", "Sea-Lake 42!", "x"]
+    assert (clip.tokenize(texts) == oracle_clip().tokenize(texts)).all()
+    t = clip.tokenize(texts)
+    assert t.shape == (4, 77) and t[0, 0] == 49406 and (t.argmax(-1) == (t == 49407).int().argmax(-1)).all()
+    assert (t[1, 1:5] == 343).all()
+    with pytest.raises(RuntimeError):
+        clip.tokenize(["word " * 100])
+
+
+def test_shard_range_covers_the_pool_in_order():
+    import grip_amd  # noqa: F401
+    from grip_amd import dist
+    for n in (0, 1, 7, 50000, 50001):
+        for ws in (1, 2, 3, 8):
+            got = []
+            per0 = None
+            for r in range(ws):
+                lo, hi, per = dist.shard_range(n, r, ws)
+                per0 = per if per0 is None else per0
+                assert per == per0 and hi - lo <= per
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+
+
+def test_fpl_row_weights_reproduce_the_three_reference_losses(golden_small):
+    """sum_i w_i CE_i with grip_amd.steps.fpl_row_weights == the reference FPL losses (golden G7)."""
+    import grip_amd  # noqa: F401
+    from grip_amd.steps import fpl_row_weights
+    g = golden_small
+    logits = torch.from_numpy(g["g7.logits"])
+    labels = torch.tensor([0, 3, 1, 4, 2, 3])
+    ce = torch.nn.functional.cross_entropy(logits, labels, reduction="none")
+    unl = [True, False, True, True, False, True]
+    w = fpl_row_weights(unl, gamma_seen=4 / 2, gamma_pseudo=1.0)                     # SSL: gamma = |unseen| / |seen|
+    np.testing.assert_allclose((w * ce).sum().numpy(), g["g7.ssl"], rtol=1e-6)
+    is_unseen = [int(l) in (3, 4) for l in labels]
+    w = fpl_row_weights(is_unseen, gamma_seen=1.0, gamma_pseudo=3 / 3)               # TRZSL: CE(seen) + gamma CE(unseen)
+    np.testing.assert_allclose((w * ce).sum().numpy(), g["g7.trzsl"], rtol=1e-6)
+    w = fpl_row_weights([False] * 6)                                                  # UL: plain mean
+    np.testing.assert_allclose((w * ce).sum().numpy(), g["g7.ul"], rtol=1e-6)
+
+
+def _cases():
+    with open(os.path.join(REPO, "tests", "golden", "leaderboard.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c["name"])
+def test_product_leaderboard_matches_reference_outputs(case):
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    n = len(case["paths"])
+    probs = np.frombuffer(bytes.fromhex(case["probs_f32_hex"]), dtype=np.float32).reshape(n, -1)
+    fp, lab = pl.leaderboard(probs, np.array(case["pred"]), case["paths"], case["label_ids"], case["k"])
+    assert fp == case["filepaths"] and lab == case["labels"]
+
+
+@pytest.mark.parametrize("n,c,k,alpha,seed", [(1, 3, 2, 1.0, 0), (64, 2, 1, 0.2, 1), (500, 13, 7, 0.5, 2), (2000, 47, 16, 0.05, 3),
+                                               (3000, 10, 3000, 1.0, 4), (1500, 102, 16, 30.0, 5)])
+def test_product_leaderboard_matches_oracles_on_random_pools(n, c, k, alpha, seed):
+    """Randomised: peaked and flat rows, quantised scores (exact ties), duplicate paths, k >= n."""
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    from oracle import cbind, leaderboard as LB
+    g = np.random.RandomState(seed)
+    probs = g.dirichlet(np.ones(c) * alpha, size=n).astype(np.float32)
+    probs[::2] = np.round(probs[::2] * 16) / 16
+    paths = [f"root/{g.randint(0, n // 2 + 1):05d}.jpg" for _ in range(n)]        # duplicates on purpose
+    pred = torch.from_numpy(probs).argmax(dim=1).numpy()
+    ids = [int(v) for v in g.permutation(c)]
+    want = cbind.leaderboard_ref(probs, pred, paths, ids, k)
+    got = pl.leaderboard(probs, pred, paths, ids, k)
+    assert got == want
+    if n <= 600:
+        assert got == LB.leaderboard_scan(probs, pred, paths, ids, k)
+
+
+def test_leaderboard_at_full_size_matches_the_c_oracle():
+    """BASELINE.json size (50 000 x 102, k = 16) + properties that hold for any input."""
+    import grip_amd  # noqa: F401
+    from grip_amd import engine, pseudolabels as pl
+    from oracle import cbind
+    g = np.random.RandomState(9)
+    n, c, k = 50000, 102, 16
+    logits = g.randn(n, c).astype(np.float32) * 4
+    probs = torch.from_numpy(logits).softmax(-1).numpy()
+    pred = probs.argmax(1)
+    paths = [f"p/{i:07d}.jpg" for i in range(n)]
+    img, cls = engine.leaderboard_scan(probs, pred, pl.path_ranks(paths), k)
+    assert len(img) <= c * k
+    for j in range(c):
+        rows = img[cls == j]
+        assert len(rows) <= k and len(set(rows.tolist())) == len(rows)
+    assert pl.leaderboard(probs, pred, paths, list(range(c)), k) == cbind.leaderboard_ref(probs, pred, paths, list(range(c)), k)
+
+
+def test_empty_pool_and_k_all():
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    assert pl.leaderboard(np.zeros((0, 4), np.float32), np.zeros(0, np.int32), [], [0, 1, 2, 3], 5) == ([], [])
+    probs = np.array([[0.1, 0.9], [0.6, 0.4]], np.float32)
+    assert pl.leaderboard(probs, np.array([1, 0]), ["a", "b"], [7, 9], pl.K_ALL) == (["a", "b"], [9, 7])
+
+
+def test_reference_prompt_string_quirks():
+    """utils/clip_pseudolabels.py:24 concatenates (literal '{}' stays); CoOp prompts are 'X .. X name'."""
+    import grip_amd  # noqa: F401
+    src = open(os.path.join(REPO, "menghini-neurips23-code_amd", "utils", "clip_pseudolabels.py")).read()
+    assert "f\"{template}{' '.join(i.split('_'))}\"" in src
+    from grip_amd.models import CustomTextEncoder
+    assert CustomTextEncoder.forward.__code__.co_varnames[:4] == ("self", "class_embeddings", "classes", "enable_pos_emb")
