@@ -53,6 +53,8 @@ struct GemmArgs {
     const half_t* A;    // [Mpad, K], lda = K; rows >= M may hold anything finite or not (never stored)
     const half_t* W;    // [N, K]
     int M, N, K;
+    int variant;        // 0 = let the launcher choose the tile shape; 1/2/3 force 128x128 / 256x256 / 256x128 (tests, tuning)
+    int64_t m_pad;      // rows allocated for A (>= M); the 256-row tile is used only when m_pad covers it
     const float* bias;  // [N] or null
     const float* resid; // [M, ldc] f32 (EPI_BIAS_RESID_F32)
     const half_t* aux;  // [M, ldc] f16 (EPI_GELUGRAD_F16)

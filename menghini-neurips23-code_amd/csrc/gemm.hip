@@ -12,6 +12,8 @@
 // 8-byte (f16) or 16-byte (f32) accesses.
 // Workgroup ids are remapped so every XCD (private 4 MiB L2) owns a contiguous run of tiles,
 // N-fastest: the A row panel and the W panel stay L2-resident across the run.
+#include <type_traits>
+
 #include "common.h"
 
 #define BM 128
@@ -23,6 +25,90 @@ __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf
 __device__ __forceinline__ float quick_gelu_grad(float x) {
     float s = 1.0f / (1.0f + __expf(-1.702f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+
+// (epilogue_rows: branch-free for workgroups whose rows are all < M; only the last M tile checks rows.)
+// Wave-private LDS transposition of the accumulators so that global accesses of the epilogue are
+// row-contiguous: a lane's fragment data (4 consecutive columns of 16 different rows per
+// instruction = 64-byte pieces) is written to a 32-row x 64-column f32 slab and read back as
+// 4 rows x 256 contiguous bytes per wave instruction; residual reads and C writes then move whole
+// 128-byte lines (f16 output: 128 B per row, f32: 256 B).  One slab per wave, no workgroup barrier.
+#define EPI_LDW 68   // slab row stride in floats: conflict-free ds_write_b128, <= 2-way ds_read_b128
+#define EPI_SLAB_FLOATS (32 * EPI_LDW)
+
+template <int EPI, int ROWFRAGS, bool CHECK>
+__device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
+    constexpr int NP = ROWFRAGS / 2;
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID_F32);
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int rr = lane >> 4, cc = (lane & 15) * 4;
+    const int col = col0 + cc;
+    const int ldc = g.ldc;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (HAS_BIAS) {
+        bias4 = *(const f32x4*)(g.bias + col);
+        asm volatile("" : "+v"(bias4));   // retire the load here: a later wait for it would also drain every store issued since
+    }
+    // operand prefetch (residual / GELU' argument): all 8 row loads of a pass are issued together, and
+    // the loads of pass p+1 go out before the stores of pass p, so no load ever queues behind a store.
+    f32x4 res[2][8];
+    half4 aux[2][8];
+    auto prefetch = [&](int p, int b) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int row = row0 + p * 32 + it * 4 + rr;
+            row = row < g.M ? row : g.M - 1;
+            const size_t o = (size_t)row * ldc + col;
+            if constexpr (EPI == EPI_BIAS_RESID_F32) res[b][it] = *(const f32x4*)(g.resid + o);
+            if constexpr (EPI == EPI_GELUGRAD_F16) aux[b][it] = *(const half4*)(g.aux + o);
+        }
+    };
+    if constexpr (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_GELUGRAD_F16) prefetch(0, 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (ii * 16 + frow) * EPI_LDW + j * 16 + fgrp * 4) = acc[2 * p + ii][j];
+        if constexpr (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_GELUGRAD_F16)
+            if (p + 1 < NP) prefetch(p + 1, (p + 1) & 1);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + rr;
+            f32x4 v = *(const f32x4*)(slab + rl * EPI_LDW + cc);
+            const int row = row0 + p * 32 + rl;
+            const size_t o = (size_t)row * ldc + col;
+            if constexpr (HAS_BIAS) v += bias4;
+            if (!CHECK || row < g.M) {
+                if constexpr (EPI == EPI_F32) {
+                    *(f32x4*)((float*)g.out + o) = v;
+                } else if constexpr (EPI == EPI_F32_SCALE) {
+                    *(f32x4*)((float*)g.out + o) = v * g.scalar;
+                } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                    *(f32x4*)((float*)g.out + o) = v + res[p & 1][it];
+                } else if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_F16) {
+                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                } else if constexpr (EPI == EPI_BIAS_GELU_F16) {
+                    if (g.out2) *(half4*)((half_t*)g.out2 + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)quick_gelu(v[0]), (half_t)quick_gelu(v[1]), (half_t)quick_gelu(v[2]), (half_t)quick_gelu(v[3])};
+                } else if constexpr (EPI == EPI_GELUGRAD_F16) {
+                    const half4 x = aux[p & 1][it];
+                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)(v[0] * quick_gelu_grad((float)x[0])), (half_t)(v[1] * quick_gelu_grad((float)x[1])),
+                                                            (half_t)(v[2] * quick_gelu_grad((float)x[2])), (half_t)(v[3] * quick_gelu_grad((float)x[3]))};
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI, int ROWFRAGS>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
+    if (row0 + ROWFRAGS * 16 <= g.M)
+        epilogue_rows_impl<EPI, ROWFRAGS, false>(g, acc, slab, row0, col0, lane);
+    else
+        epilogue_rows_impl<EPI, ROWFRAGS, true>(g, acc, slab, row0, col0, lane);
 }
 
 template <int EPI>
@@ -105,46 +191,156 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
         }
     }
 
-    // ---- epilogue: lane holds C[row = m0 + wr*64 + i*16 + (lane&15)][col = n0 + wc*64 + j*16 + (lane>>4)*4 + 0..3]
-    const int ldc = g.ldc;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wr * 64 + i * 16 + frow;
-        if (row >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wc * 64 + j * 16 + fgrp * 4;
-            f32x4 v = acc[i][j];
-            const size_t o = (size_t)row * ldc + col;
-            if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID_F32) {
-                const f32x4 b = *(const f32x4*)(g.bias + col);
-                v += b;
-            }
-            if constexpr (EPI == EPI_F32) {
-                *(f32x4*)((float*)g.out + o) = v;
-            } else if constexpr (EPI == EPI_F32_SCALE) {
-                *(f32x4*)((float*)g.out + o) = v * g.scalar;
-            } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
-                const f32x4 r = *(const f32x4*)(g.resid + o);
-                *(f32x4*)((float*)g.out + o) = v + r;
-            } else if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_F16) {
-                half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *(half4*)((half_t*)g.out + o) = h;
-            } else if constexpr (EPI == EPI_BIAS_GELU_F16) {
-                if (g.out2) {
-                    half4 p = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *(half4*)((half_t*)g.out2 + o) = p;
-                }
-                half4 h = {(half_t)quick_gelu(v[0]), (half_t)quick_gelu(v[1]), (half_t)quick_gelu(v[2]), (half_t)quick_gelu(v[3])};
-                *(half4*)((half_t*)g.out + o) = h;
-            } else if constexpr (EPI == EPI_GELUGRAD_F16) {
-                const half4 x = *(const half4*)(g.aux + o);
-                half4 h = {(half_t)(v[0] * quick_gelu_grad((float)x[0])), (half_t)(v[1] * quick_gelu_grad((float)x[1])),
-                           (half_t)(v[2] * quick_gelu_grad((float)x[2])), (half_t)(v[3] * quick_gelu_grad((float)x[3]))};
-                *(half4*)((half_t*)g.out + o) = h;
-            }
-        }
+    __syncthreads();   // every wave is done with the stage buffers: reuse them as epilogue slabs
+    epilogue_rows<EPI, 4>(g, acc, (float*)lds + wave * EPI_SLAB_FLOATS, m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-problem variants: BM x BN x 32 block tile, one wave per 128x64 sub-tile (8x4 fragments, 128
+// accumulator registers, 32 MFMA per 12 ds_read_b128 per K tile):
+//     256x256: 8 waves, 4-stage ring (128 KiB LDS, one workgroup per CU), 128 FLOP per staged byte;
+//     256x128: 4 waves, 3-stage ring ( 72 KiB LDS, two workgroups per CU), 85 FLOP per staged byte --
+//              the two co-resident workgroups run out of phase, so one's barrier / ds_read / epilogue
+//              time is covered by the other's MFMAs.
+// The ring is fed by global_load_lds; the loads of tile t+D (D = stages-1) are issued while tile t is
+// being multiplied and are retired with COUNTED waits (s_waitcnt vmcnt((D-1)*G), G = loads per wave per
+// tile: "everything but the D-1 youngest tiles") followed by one raw s_barrier per K tile, so L2/HBM
+// latency is covered by several tiles of MFMA work (guide: 3-buffer glds + raw barrier).
+// Rows of a 32-wide K tile are 64 B = four 16-byte chunks; the chunk index is XORed with
+// T[(row >> 2) & 3], T = {0,2,3,1}, on the SOURCE address and on the read: ds_read_b128 conflict-free.
+#define BK2 32
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, int BMT, int BNT, int NSTAGE>
+__global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int WN = BNT / 64;                  // waves along N
+    constexpr int NW = (BMT / 128) * WN;          // waves per workgroup
+    constexpr int STAGE = (BMT + BNT) * BK2;      // halfs per stage
+    constexpr int GA = BMT / 16 / NW, GB = BNT / 16 / NW;   // global_load_lds per wave per tile (A rows, W rows)
+    constexpr int G = GA + GB;
+    extern __shared__ __attribute__((aligned(16))) half_t lds2[];
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BMT, n0 = tn * BNT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave - wr * WN;
+
+    // staging: wave w fills A rows [w*GA*16, +GA*16) and W rows [w*GB*16, +GB*16), 16 rows per instruction
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((0x1320 >> (((lane >> 4) & 3) * 4)) & 3);
+    const size_t K = (size_t)g.K;
+    const half_t* a_src = g.A + (size_t)(m0 + wave * GA * 16 + srow) * K + schunk * 8;
+    const half_t* w_src = g.W + (size_t)(n0 + wave * GB * 16 + srow) * K + schunk * 8;
+
+    auto stage = [&](int buf, int kt) {
+        half_t* abase = lds2 + buf * STAGE + wave * GA * 16 * BK2;
+        half_t* bbase = lds2 + buf * STAGE + BMT * BK2 + wave * GB * 16 * BK2;
+        const half_t* as = a_src + (size_t)kt * BK2;
+        const half_t* ws = w_src + (size_t)kt * BK2;
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 16 * K), (AS3 void*)(abase + i * 16 * BK2), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GB; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 16 * K), (AS3 void*)(bbase + i * 16 * BK2), 16, 0, 0);
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fchunk = fgrp ^ ((0x1320 >> (((lane >> 2) & 3) * 4)) & 3);
+    const int a_off = (wr * 128 + frow) * BK2 + fchunk * 8;
+    const int b_off = BMT * BK2 + (wc * 64 + frow) * BK2 + fchunk * 8;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Fragment registers are double-buffered (set 0 / set 1): while the 32 MFMAs of tile t run on one
+    // set, the 12 ds_read_b128 of tile t+1 fill the other, so the LDS read phase that all waves of a
+    // workgroup enter together right after the barrier is hidden behind matrix work.
+    half8 fa[2][8], fb[2][4];
+    auto load_frags = [&](int set, int buf) {
+        const half_t* st = lds2 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = *(const half8*)(st + b_off + j * 16 * BK2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[set][i] = *(const half8*)(st + a_off + i * 16 * BK2);
+    };
+    auto mfma_set = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+    };
+
+    const int nk = g.K / BK2;   // >= NSTAGE (checked by the launcher)
+    constexpr int D = NSTAGE;   // tiles in flight: a tile's LDS slot is free once its fragments are in registers
+    // One K step.  On entry fragment set SET holds (or is receiving) tile kt.  WAITN = vmcnt that leaves
+    // only the tiles younger than kt+1 outstanding; the barrier then certifies tile kt+1 for every wave
+    // and -- because each wave drained its own LDS reads first -- frees the slot of tile kt.
+    auto step = [&](auto set_c, auto wait_c, auto has_next_c, int kt) {
+        constexpr int SET = decltype(set_c)::value;
+        constexpr int WAITN = decltype(wait_c)::value;
+        constexpr bool HAS_NEXT = decltype(has_next_c)::value;
+        if constexpr (HAS_NEXT) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_vmcnt<WAITN>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + D < nk) stage(kt % NSTAGE, kt + D);
+            load_frags(SET ^ 1, (kt + 1) % NSTAGE);
+        }
+        mfma_set(SET);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using WS = std::integral_constant<int, (D - 2) * G>;   // steady state
+    using YES = std::true_type;
+    using NO = std::false_type;
+
+#pragma unroll
+    for (int t = 0; t < D; ++t) stage(t, t);
+    wait_vmcnt<(D - 1) * G>();
+    __builtin_amdgcn_s_barrier();        // tile 0 certified
+    const int R = nk - (D - 1);          // steady-state steps (kt = 0 .. nk-D); the last D-1 steps drain
+    int kt = 0;
+    if (R & 1) {
+        load_frags(1, 0);
+        step(I1{}, WS{}, YES{}, 0);
+        kt = 1;
+    } else {
+        load_frags(0, 0);
+    }
+    for (; kt < R; kt += 2) {
+        step(I0{}, WS{}, YES{}, kt);
+        step(I1{}, WS{}, YES{}, kt + 1);
+    }
+    if constexpr (D == 4) {
+        step(I0{}, std::integral_constant<int, G>{}, YES{}, kt);
+        step(I1{}, std::integral_constant<int, 0>{}, YES{}, kt + 1);
+        step(I0{}, I0{}, NO{}, kt + 2);
+    } else {
+        static_assert(D == 3, "ring depth 3 or 4");
+        step(I0{}, std::integral_constant<int, 0>{}, YES{}, kt);
+        step(I1{}, I0{}, NO{}, kt + 1);
+    }
+
+    __builtin_amdgcn_s_barrier();   // every wave is done with the ring: reuse it as epilogue slabs
+    epilogue_rows<EPI, 8>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 // ---- optional in-library timing of the GEMM launches (uniform 1-in-4 sample) (HIP events on the launch stream), used by
@@ -218,9 +414,67 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     return rc;
 }
 
+template <int BMT, int BNT, int NSTAGE>
+static int launch_big(int epi, const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.N / BNT;
+    constexpr size_t lds = (size_t)NSTAGE * (BMT + BNT) * BK2 * 2;
+    constexpr int threads = (BMT / 128) * (BNT / 64) * 64;
+    dim3 grid(tiles_m * tiles_n), block(threads);
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<E, BMT, BNT, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_big_kernel<E, BMT, BNT, NSTAGE>), grid, block, lds, s, a, tiles_m, tiles_n);               \
+    } break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_F32)
+        GRIP_GEMM_CASE(EPI_F16)
+        GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
+        GRIP_GEMM_CASE(EPI_F32_SCALE)
+        default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage), 3 = 256x128x32 (3-stage)
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s) {
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
+    const int64_t m256 = (int64_t)((a.M + 255) / 256) * 256;
+    const bool can_big = a.m_pad >= m256 && a.K >= 4 * BK2;       // A must be padded to the 256-row tile
+    int variant = a.variant;
+    if (variant == 0) {
+        // pick the tile shape by (measured relative rate) x (fill of the last wave of workgroups over
+        // 256 CUs): 256x256 runs one workgroup per CU, the other two shapes two per CU.
+        auto fill = [](int64_t tiles, int64_t slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
+        const int64_t tm128 = (a.M + 127) / 128, tm256 = m256 / 256;
+        double best = 0.85 * fill(tm128 * (a.N / 128), 512);
+        variant = 1;
+        if (can_big) {
+            const double s3 = 0.93 * fill(tm256 * (a.N / 128), 512);
+            if (s3 > best) { best = s3; variant = 3; }
+            if (a.N % 256 == 0) {
+                const double s2 = 1.0 * fill(tm256 * (a.N / 256), 256);
+                if (s2 > best) { best = s2; variant = 2; }
+            }
+        }
+    }
+    if (variant == 2) {
+        GRIP_REQUIRE(can_big && a.N % 256 == 0, "gemm: 256x256 tile needs N %% 256 == 0 and A padded to 256 rows");
+        return launch_big<256, 256, 4>(epi, a, s);
+    }
+    if (variant == 3) {
+        GRIP_REQUIRE(can_big, "gemm: 256x128 tile needs A padded to 256 rows");
+        return launch_big<256, 128, 3>(epi, a, s);
+    }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     dim3 grid(tiles_m * tiles_n), block(256);
 #define GRIP_GEMM_CASE(E) \

@@ -189,8 +189,8 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     GRIP_REQUIRE(D.kind == 0 || P < D.seq0 - 1, "text: n_prefix %d does not fit the context", P);
     GRIP_REQUIRE(w.S <= 608, "sequence length %d exceeds the fused-attention limit 608", w.S);
     w.M = batch * w.S;
-    w.Mp = round_up64(w.M, 128);
-    const int64_t Bp = round_up64(batch, 128);
+    w.Mp = round_up64(w.M, 256);
+    const int64_t Bp = round_up64(batch, 256);
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return (void*)p; };
     if (!train) w.x = (float*)take(w.Mp * d * 4);
@@ -200,7 +200,7 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     w.cls16 = (half_t*)take(Bp * d * 2);
     if (D.kind == 0) {
         const int64_t G2 = D.seq0 - 1;
-        const int64_t prow = round_up64(batch * G2, 128);
+        const int64_t prow = round_up64(batch * G2, 256);
         GRIP_REQUIRE(prow * t->L.kpad <= w.Mp * 4 * d, "internal: patch buffer does not fit its alias");
         w.patches = w.h;
         w.patch_out = (float*)take(batch * G2 * d * 4);
@@ -292,19 +292,19 @@ static int run_blocks(grip_tower* t, Workspace& w, float* x0, int causal, hipStr
         float* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
         RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, w.M, d, s));
         GemmArgs a{};
-        a.A = w.xn; a.W = W + lw.in_w; a.M = w.M; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
+        a.A = w.xn; a.W = W + lw.in_w; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
         RUN(launch_gemm(EPI_BIAS_F16, a, s));
         RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
         a = GemmArgs{};
-        a.A = att; a.W = W + lw.out_w; a.M = w.M; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
+        a.A = att; a.W = W + lw.out_w; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
         RUN(launch_gemm(EPI_BIAS_RESID_F32, a, s));
         RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, w.M, d, s));
         a = GemmArgs{};
-        a.A = w.xn; a.W = W + lw.fc_w; a.M = w.M; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.h; a.ldc = 4 * d;
+        a.A = w.xn; a.W = W + lw.fc_w; a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.h; a.ldc = 4 * d;
         a.out2 = w.train ? w.hpre_l[(size_t)l] : nullptr;
         RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
         a = GemmArgs{};
-        a.A = w.h; a.W = W + lw.proj_w; a.M = w.M; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
+        a.A = w.h; a.W = W + lw.proj_w; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
         RUN(launch_gemm(EPI_BIAS_RESID_F32, a, s));
         x = x_out;
     }
@@ -335,7 +335,7 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         const float* F = t->w32;
         RUN(launch_im2col(images, images_f16, w.patches, batch, D.resolution, D.patch, t->L.kpad, s));
         GemmArgs a{};
-        a.A = w.patches; a.W = W + t->L.conv_w; a.M = batch * G2; a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
+        a.A = w.patches; a.W = W + t->L.conv_w; a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         float* x0 = train ? w.x_in[0] : w.x;
         RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, batch, G2, d, s));
@@ -382,9 +382,10 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
 // Kernel-level entry points for the unit parity tests (tests/test_gpu_kernels.py).  Not part of the
 // drop-in ABI (not declared in include/grip_amd.h); they launch exactly the kernels the towers use.
 extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const float* resid,
-                               const void* aux, void* out, void* out2, float scalar, void* stream) {
+                               const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream) {
     GemmArgs a{};
-    a.A = (const half_t*)A; a.W = (const half_t*)W; a.M = M; a.N = N; a.K = K; a.bias = bias; a.resid = resid;
+    a.variant = variant;
+    a.A = (const half_t*)A; a.W = (const half_t*)W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid;
     a.aux = (const half_t*)aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
     return launch_gemm(epi, a, (hipStream_t)stream);
 }
@@ -406,18 +407,18 @@ static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, hipStrea
         const LayerW& lw = t->L.layer[(size_t)l];
         GemmArgs a{};
         // d(pre-activation) = (dx @ W_proj) * quickgelu'(h_pre)
-        a.A = w.dxh; a.W = W + lw.proj_wT; a.M = w.M; a.N = 4 * d; a.K = d; a.aux = w.hpre_l[(size_t)l]; a.out = w.dh; a.ldc = 4 * d;
+        a.A = w.dxh; a.W = W + lw.proj_wT; a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.aux = w.hpre_l[(size_t)l]; a.out = w.dh; a.ldc = 4 * d;
         RUN(launch_gemm(EPI_GELUGRAD_F16, a, s));
         a = GemmArgs{};
-        a.A = w.dh; a.W = W + lw.fc_wT; a.M = w.M; a.N = d; a.K = 4 * d; a.out = w.dln; a.ldc = d;
+        a.A = w.dh; a.W = W + lw.fc_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.out = w.dln; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         RUN(launch_ln_bwd_add(w.x_mid[(size_t)l], w.dln, F + lw.ln2_g, w.dx, w.dxh, w.M, d, s));
         a = GemmArgs{};
-        a.A = w.dxh; a.W = W + lw.out_wT; a.M = w.M; a.N = d; a.K = d; a.out = w.datt; a.ldc = d;
+        a.A = w.dxh; a.W = W + lw.out_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.out = w.datt; a.ldc = d;
         RUN(launch_gemm(EPI_F16, a, s));
         RUN(launch_attention_bwd(w.qkv_l[(size_t)l], w.att_l[(size_t)l], w.datt, w.dqkv, w.batch, w.S, H, causal, s));
         a = GemmArgs{};
-        a.A = w.dqkv; a.W = W + lw.in_wT; a.M = w.M; a.N = d; a.K = 3 * d; a.out = w.dln; a.ldc = d;
+        a.A = w.dqkv; a.W = W + lw.in_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 3 * d; a.out = w.dln; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         RUN(launch_ln_bwd_add(w.x_in[(size_t)l], w.dln, F + lw.ln1_g, w.dx, w.dxh, w.M, d, s));
     }

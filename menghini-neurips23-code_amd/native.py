@@ -47,7 +47,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)   # the drop-in ABI (include/grip_amd.h)
 _DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of the ABI
-    "grip_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "grip_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]),
     "grip_debug_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "grip_profile_enable": (c_int, [c_int]),
     "grip_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),

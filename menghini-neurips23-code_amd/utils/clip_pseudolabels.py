@@ -30,7 +30,7 @@ def _pool_images(dataset, transform, device):
 
 
 def compute_pseudo_labels(k, template, dataset, classnames, transform, clip_model, label_to_idx, device, filename,
-                          chunk=256):
+                          chunk=220):
     prompts = [f"{template}{' '.join(i.split('_'))}" for i in classnames]     # reference :24 (literal "{}" kept)
     text = clip.tokenize(prompts).to(device)
     with torch.no_grad():

@@ -26,11 +26,17 @@ def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (3408, 2304, 768), (77 * 5, 512, 2048), (16, 512, 768)])
-def test_gemm_epilogues(M, N, K):
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (3408, 2304, 768), (77 * 5, 512, 2048), (16, 512, 768),
+                                   (50432, 768, 768), (12700, 2304, 768), (25000, 768, 3072), (16500, 3072, 768), (50000, 512, 128)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_gemm_epilogues(M, N, K, variant):
+    if variant == 2 and N % 256:
+        pytest.skip("256x256 tile needs N % 256 == 0")
+    if variant in (2, 3) and K < 128:
+        pytest.skip("ring needs K >= 128")
     native, lib = _lib()
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
-    Mp = (M + 127) // 128 * 128
+    Mp = (M + 255) // 256 * 256     # rows allocated for A: lets the launcher pick the 256-row tile for large problems
     A = torch.randn(Mp, K, device="cuda", generator=g).half()
     A[M:] = float("nan")  # padding rows must never leak into stored rows
     W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
@@ -41,29 +47,43 @@ def test_gemm_epilogues(M, N, K):
     tol = dict(rtol=2e-3, atol=2e-3)
 
     out = torch.full((M, N), 7.0, device="cuda")
-    native.check(lib.grip_debug_gemm(0, _p(A), _p(W), M, N, K, None, None, None, _p(out), None, 1.0, _stream()))
+    native.check(lib.grip_debug_gemm(0, _p(A), _p(W), M, N, K, None, None, None, _p(out), None, 1.0, Mp, variant, _stream()))
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)   # EPI_F32: only f32 summation order differs
 
     out16 = torch.zeros(M, N, device="cuda", dtype=torch.float16)
-    native.check(lib.grip_debug_gemm(1, _p(A), _p(W), M, N, K, _p(bias), None, None, _p(out16), None, 1.0, _stream()))
+    native.check(lib.grip_debug_gemm(1, _p(A), _p(W), M, N, K, _p(bias), None, None, _p(out16), None, 1.0, Mp, variant, _stream()))
     torch.testing.assert_close(out16.float(), ref + bias, **tol)
 
     pre = torch.zeros(M, N, device="cuda", dtype=torch.float16)
-    native.check(lib.grip_debug_gemm(2, _p(A), _p(W), M, N, K, _p(bias), None, None, _p(out16), _p(pre), 1.0, _stream()))
+    native.check(lib.grip_debug_gemm(2, _p(A), _p(W), M, N, K, _p(bias), None, None, _p(out16), _p(pre), 1.0, Mp, variant, _stream()))
     torch.testing.assert_close(out16.float(), quick_gelu(ref + bias), **tol)
     torch.testing.assert_close(pre.float(), ref + bias, **tol)
 
-    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), None, _p(out), None, 1.0, _stream()))
+    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), None, _p(out), None, 1.0, Mp, variant, _stream()))
     torch.testing.assert_close(out, ref + bias + resid, rtol=1e-4, atol=1e-4)
     # in place (out aliases resid), as the inference path uses it
     r2 = resid.clone()
-    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(r2), None, _p(r2), None, 1.0, _stream()))
+    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(r2), None, _p(r2), None, 1.0, Mp, variant, _stream()))
     torch.testing.assert_close(r2, ref + bias + resid, rtol=1e-4, atol=1e-4)
 
-    native.check(lib.grip_debug_gemm(5, _p(A), _p(W), M, N, K, None, None, _p(aux), _p(out16), None, 1.0, _stream()))
+    native.check(lib.grip_debug_gemm(5, _p(A), _p(W), M, N, K, None, None, _p(aux), _p(out16), None, 1.0, Mp, variant, _stream()))
     x = aux.float()
     s = torch.sigmoid(1.702 * x)
     torch.testing.assert_close(out16.float(), ref * (s * (1 + 1.702 * x * (1 - s))), **tol)
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_gemm256_is_not_transposed(variant):
+    """Same transpose check through the 256x256 tile path (large M)."""
+    native, lib = _lib()
+    M, N, K = 256 * 64, 768, 128
+    A = torch.zeros(M, K, device="cuda", dtype=torch.float16)
+    idx = torch.arange(M, device="cuda")
+    A[idx, idx % K] = 1.0
+    W = ((torch.arange(N * K, device="cuda").reshape(N, K) * 7) % 97).half()
+    out = torch.zeros(M, N, device="cuda")
+    native.check(lib.grip_debug_gemm(0, _p(A), _p(W), M, N, K, None, None, None, _p(out), None, 1.0, M, variant, _stream()))
+    torch.testing.assert_close(out, W.float().t()[idx % K])
 
 
 def test_gemm_is_not_transposed():
@@ -72,7 +92,7 @@ def test_gemm_is_not_transposed():
     A = torch.eye(128, device="cuda").half()
     W = (torch.arange(128 * 128, device="cuda").reshape(128, 128) % 97).half()
     out = torch.zeros(128, 128, device="cuda")
-    native.check(lib.grip_debug_gemm(0, _p(A), _p(W), 128, 128, 128, None, None, None, _p(out), None, 1.0, _stream()))
+    native.check(lib.grip_debug_gemm(0, _p(A), _p(W), 128, 128, 128, None, None, None, _p(out), None, 1.0, 128, 0, _stream()))
     torch.testing.assert_close(out, W.float().t())
 
 

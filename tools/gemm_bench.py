@@ -1,0 +1,45 @@
+"""Developer probe: TFLOP/s of the GEMM kernels per projection shape (random operands)."""
+import ctypes
+import sys
+
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import grip_amd  # noqa: E402
+from grip_amd import native  # noqa: E402
+
+lib = native.lib()
+
+
+def p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def run(M, N, K, epi, variant, reps=20):
+    Mp = (M + 255) // 256 * 256
+    A = torch.randn(Mp, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+    if __import__("os").environ.get("ZERO"):
+        A.zero_(); W.zero_()
+    bias = torch.randn(N, device="cuda")
+    resid = torch.randn(M, N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi in (0, 3) else torch.float16)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    f = lambda: native.check(lib.grip_debug_gemm(epi, p(A), p(W), M, N, K, p(bias), p(resid), None, p(out), None, 1.0, Mp, variant, s))
+    for _ in range(3):
+        f()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
+imgs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+M = imgs * 197
+for name, N, K, epi in [("qkv", 2304, 768, 1), ("out", 768, 768, 3), ("fc", 3072, 768, 2), ("proj", 768, 3072, 3), ("f32", 768, 768, 0)]:
+    r = [run(M, N, K, epi, v) for v in (1, 2, 3, 0)]
+    print(f"{name:5s} M={M} N={N} K={K}: " + " | ".join(f"{nm} {m:.3f} ms {t:.0f} TF/s" for nm, (m, t) in zip(("128x128", "256x256", "256x128", "auto"), r)), flush=True)
