@@ -349,7 +349,7 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
 #include <deque>
 #include <vector>
 namespace {
-constexpr int PROF_RING = 4096, PROF_EPIS = 8;
+constexpr int PROF_RING = 4096, PROF_EPIS = 32;   // slot = variant * 8 + epilogue id
 struct ProfRec { int epi; double flops; hipEvent_t a, b; };
 bool g_prof = false;
 std::deque<ProfRec> g_recs;
@@ -385,7 +385,7 @@ extern "C" int grip_profile_enable(int on) {
     return GRIP_OK;
 }
 
-// Per epilogue id e in [0, n): launches[e], total milliseconds, total algorithmic FLOPs (2*M*N*K) of
+// Per slot (variant * 8 + epilogue id) in [0, n): launches[slot], total milliseconds, total algorithmic FLOPs (2*M*N*K) of
 // every GEMM launched since grip_profile_enable(1).  Synchronises the outstanding events.
 extern "C" int grip_profile_collect(int n, int64_t* launches, double* total_ms, double* total_flops) {
     prof_drain(0);
@@ -397,19 +397,21 @@ extern "C" int grip_profile_collect(int n, int64_t* launches, double* total_ms, 
     return GRIP_OK;
 }
 
-static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s);
+static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen);
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     // sample every 4th launch: the launch sequence is periodic with an odd period (49 GEMMs per
     // encode chunk), so every kernel/shape is sampled uniformly while the markers cost < 1 %
     static unsigned g_tick = 0;
-    if (!g_prof || (++g_tick & 3u)) return launch_gemm_impl(epi, a, s);
+    int chosen = 0;
+    if (!g_prof || (++g_tick & 3u)) return launch_gemm_impl(epi, a, s, &chosen);
     if ((int)g_recs.size() >= PROF_RING) prof_drain(PROF_RING / 2);
     ProfRec r{epi, 2.0 * a.M * (double)a.N * a.K, prof_event(), prof_event()};
-    if (!r.a || !r.b) return launch_gemm_impl(epi, a, s);
+    if (!r.a || !r.b) return launch_gemm_impl(epi, a, s, &chosen);
     (void)hipEventRecord(r.a, s);
-    const int rc = launch_gemm_impl(epi, a, s);
+    const int rc = launch_gemm_impl(epi, a, s, &chosen);
     (void)hipEventRecord(r.b, s);
+    r.epi = chosen * 8 + epi;
     g_recs.push_back(r);
     return rc;
 }
@@ -445,7 +447,7 @@ static int launch_big(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 // variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage), 3 = 256x128x32 (3-stage)
-static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s) {
+static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
     const int64_t m256 = (int64_t)((a.M + 255) / 256) * 256;
@@ -467,6 +469,7 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s) {
             }
         }
     }
+    *chosen = variant;
     if (variant == 2) {
         GRIP_REQUIRE(can_big && a.N % 256 == 0, "gemm: 256x256 tile needs N %% 256 == 0 and A padded to 256 rows");
         return launch_big<256, 256, 4>(epi, a, s);
