@@ -120,6 +120,17 @@ class Loop:
         self.train_steps = n_steps
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in
+    separate rocprofv3 --pmc runs of this same script; profiles/r01_traffic.json), or None."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)["kernels"]
+        return t[kernel.split(" [")[0]]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/, a port of the reference path: kind "port") on a bounded sample.
     R-mode = reference-faithful loop of utils/clip_pseudolabels.py:31-41: batch 1, the full
@@ -231,7 +242,7 @@ def main():
         "roofline": {
             "bound": "mfma", "kernel": kname(dom),
             "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-            "traffic": None,
+            "traffic": hbm_traffic(kname(dom)),
             "launches_timed": int(launches[dom]), "avg_launch_ms": ms[dom] / max(launches[dom], 1),
             "all_gemm": {kname(i): {"launches": int(launches[i]), "ms": round(float(ms[i]), 3),
                                         "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1) if ms[i] > 0 else None}
