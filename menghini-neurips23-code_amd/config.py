@@ -43,6 +43,8 @@ CLIP_CONFIGS = {
     # test-only shapes: head dim is always 64 (as in every CLIP ViT), widths are
     # multiples of 128 so the MFMA GEMM tiles apply unchanged.
     "tiny": _D("tiny", 128, 32, 2, 128, 8, 77, 49408, 128, 2, 2),
+    # ViT-L/14@336px geometry (patch 14 -> K = 588 padded to 640, S = 577) at test width
+    "tinyL336": _D("tinyL336", 128, 336, 2, 128, 14, 77, 49408, 128, 2, 2),
     "small": _D("small", 256, 64, 3, 256, 16, 77, 49408, 256, 4, 2),
 }
 

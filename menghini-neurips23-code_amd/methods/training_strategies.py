@@ -1,0 +1,329 @@
+"""Stand-in for the reference's MISSING `methods/*/training_strategies.py` (every strategy file does
+`from .training_strategies import TrainingStrategy`, but the file is absent upstream: SURVEY.md 0.2).
+The contract is reconstructed from the call sites and from `pseudo_iterative.py:62-125`
+(GRIP schedule).  Everything that cannot be pinned from the snapshot is an explicit config knob with a
+documented default: prompt-init seed (`OPTIM_SEED`), `MOMENTUM` (0), loader shuffle seed, best-epoch rule
+(highest validation accuracy, first wins).  Training trajectories are therefore NOT claimed to match
+upstream bit for bit; the per-step numerics are the parity-tested kernels.
+
+One class covers the three prompt modalities (config.MODALITY in {"text", "image", "multi"}) and the three
+learning paradigms (config.LEARNING_PARADIGM in {"ssl", "ul", "trzsl"}); the reference's eighteen strategy
+classes are thin aliases of it (methods/strategies.py).
+"""
+import copy
+import logging
+import math
+
+import numpy as np
+import torch
+
+from .. import clip, dist as gdist, pseudolabels as pl, steps
+from ..engine import cosine_head
+from ..models import CustomImageEncoder, CustomTextEncoder, ImagePrefixModel, TextPrefixModel, UPTModel
+from ..utils import pseudolabel_top_k
+
+log = logging.getLogger(__name__)
+
+
+def make_scheduler(optimizer, config):
+    """WarmupCosineSchedule stepped once per EPOCH (utils/schedulers.py:36-65 of the reference)."""
+    warm, total = int(getattr(config, "WARMUP_EPOCHS", 0)), int(config.EPOCHS)
+
+    def lr_lambda(step):
+        if step < warm:
+            return float(step) / float(max(1.0, warm))
+        progress = float(step - warm) / float(max(1, total - warm))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+
+
+class TrainingStrategy:
+    def __init__(self, config, label_to_idx, classes, seen_classes, unseen_classes, device, data_folder=None):
+        self.config = config
+        self.classes, self.seen_classes, self.unseen_classes = classes, seen_classes, unseen_classes
+        self.label_to_idx = label_to_idx
+        self.device = device
+        self.data_folder = data_folder
+        self.clip_model, self.transform = clip.load(config.VIS_ENCODER, device=device)
+        self.template = config.PROMPT_TEMPLATE
+        self.modality = config.MODALITY
+        self.paradigm = getattr(config, "LEARNING_PARADIGM", "ssl")
+        self.val_unseen_files = self.val_unseen_labs = None
+        self.balance_param = 1.0
+        self.check_unlabeled = set()
+        self.declare_custom_encoder()
+        self.initialize_prompts_parameters()
+
+    # ------------------------------------------------------------------ encoders / prompts / model
+    def declare_custom_encoder(self):
+        self.image_encoder = CustomImageEncoder(self.clip_model.visual) if self.modality in ("image", "multi") else None
+        self.text_encoder = CustomTextEncoder(self.clip_model, self.device, torch.float32) if self.modality in ("text", "multi") else None
+
+    def initialize_prompts_parameters(self):
+        c = self.config
+        g = torch.Generator().manual_seed(int(getattr(c, "OPTIM_SEED", 0)))
+        mean, std = float(getattr(c, "MEAN_INIT", 0.0)), float(getattr(c, "VAR_INIT", 0.02))
+        d = self.clip_model.dims
+
+        def init(*shape):
+            if getattr(c, "VIS_PREFIX_INIT", "normal") == "uniform":
+                return (torch.rand(*shape, generator=g) * 2 - 1) * std + mean
+            return torch.randn(*shape, generator=g) * std + mean
+        if self.modality == "text":
+            self.initial_prefix = init(1, int(c.PREFIX_SIZE), d.transformer_width)
+        elif self.modality == "image":
+            self.initial_prefix = init(int(c.PREFIX_SIZE), d.vision_width)
+        else:
+            self.coop_init = init(1, int(c.TEXT_PREFIX_SIZE), d.transformer_width)
+            self.vpt_init = init(1, int(c.VISION_PREFIX_SIZE), d.vision_width)
+
+    def define_model(self, classes=None):
+        c, dev = self.config, self.device
+        classes = classes if classes is not None else self.classes
+        if self.modality == "text":
+            self.model = TextPrefixModel(self.initial_prefix.clone().to(dev), self.text_encoder, classes, device=dev)
+        elif self.modality == "image":
+            self.model = ImagePrefixModel(self.initial_prefix.clone().to(dev), self.image_encoder, device=dev)
+        else:
+            torch.manual_seed(int(getattr(c, "OPTIM_SEED", 0)))
+            self.model = UPTModel(self.coop_init.clone().to(dev), self.vpt_init.clone().to(dev), None, self.image_encoder,
+                                  self.text_encoder, classes, int(getattr(c, "TRANSFORMER_DIM", 128)), device=dev, dtype=torch.float32)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.SGD(params, lr=float(c.LR), weight_decay=float(c.DECAY), momentum=float(getattr(c, "MOMENTUM", 0.0)))
+        self.scheduler = make_scheduler(self.optimizer, c)
+        self.loss_func = torch.nn.CrossEntropyLoss()
+
+    def unwrap_model(self):
+        return self.model
+
+    def training_model(self, img):
+        return self.model(img)
+
+    def backpropagate(self):
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+
+    def update_scheduler(self):
+        self.scheduler.step()
+
+    def prompt_snapshot(self):
+        m = self.unwrap_model()
+        if self.modality in ("text", "image"):
+            return [m.prefix.detach().cpu().numpy()]
+        return copy.deepcopy({k: v.detach().cpu() for k, v in m.state_dict().items()})
+
+    # ------------------------------------------------------------------ features
+    def text_prompts(self, classes):
+        return [self.template.format(" ".join(i.split("_"))) for i in classes]
+
+    @torch.no_grad()
+    def fixed_text_features(self, classes):
+        return self.clip_model.encode_text(clip.tokenize(self.text_prompts(classes)).to(self.device))
+
+    def scale(self):
+        return self.clip_model.logit_scale.exp().item()
+
+    def features(self, images, classes):
+        """(image_features, text_features) of the CURRENT model, autograd-ready where prompts are involved."""
+        if self.modality == "text":
+            self.model.classes = classes
+            with torch.no_grad():
+                img = self.clip_model.encode_image(images)
+            return img, self.model(classes)
+        if self.modality == "image":
+            return self.model(images), self.fixed_text_features(classes)
+        self.model.classes = classes
+        txt, img = self.model(images, classes)
+        return img, txt
+
+    # ------------------------------------------------------------------ datasets
+    def create_training_dataset(self, train_data, unlabeled_data=None):
+        """Plain strategies train on the labeled seen data as is; FPL strategies (subclass hook `fpl`)
+        add CLIP pseudolabels for the unlabeled pool (e.g. textual_fpl.py:51-121 of each paradigm)."""
+        if not getattr(self, "fpl", False) or unlabeled_data is None:
+            return train_data
+        c = self.config
+        pseudo_classes = self.classes if self.paradigm in ("ssl", "ul") else self.unseen_classes
+        pseudolabel_top_k(c, c.DATASET_NAME, int(c.N_PSEUDOSHOTS), self.template, unlabeled_data, pseudo_classes, self.transform,
+                          self.clip_model, self.label_to_idx, self.device, c.VIS_ENCODER, getattr(c, "SPLIT_SEED", 0))
+        return self.merge_pseudolabels(train_data, unlabeled_data)
+
+    def merge_pseudolabels(self, train_data, unlabeled_data):
+        c = self.config
+        unseen_imgs, unseen_labs = list(unlabeled_data.filepaths), [int(l) for l in unlabeled_data.labels]
+        if int(c.N_PSEUDOSHOTS) >= 10:     # hold out part of the pseudolabels for validation (textual_fpl.py:84-103)
+            np.random.seed(int(getattr(c, "validation_seed", 0)))
+            tr = np.random.choice(range(len(unseen_imgs)), size=int(len(unseen_imgs) * float(c.ratio_train_val)), replace=False)
+            va = sorted(set(range(len(unseen_imgs))).difference(set(tr.tolist())))
+            self.val_unseen_files = [unseen_imgs[i] for i in va]
+            self.val_unseen_labs = [unseen_labs[i] for i in va]
+            unseen_imgs, unseen_labs = [unseen_imgs[i] for i in tr], [unseen_labs[i] for i in tr]
+        else:
+            self.val_unseen_files = self.val_unseen_labs = None
+        self.check_unlabeled = set(p.split("/")[-1] for p in unseen_imgs)
+        if self.paradigm == "ul":
+            train_data.filepaths, train_data.labels = unseen_imgs, unseen_labs
+            self.balance_param = 1.0
+        else:
+            seen_imgs = list(train_data.filepaths)
+            seen_labs = [l if train_data.label_id else self.label_to_idx[l] for l in train_data.labels]
+            n_u, n_s = max(len(unseen_imgs), 1), max(len(seen_imgs), 1)
+            if self.paradigm == "ssl":
+                self.balance_param = math.sqrt(n_u / n_s) if self.modality == "multi" else n_u / n_s
+            else:
+                self.balance_param = n_s / n_u
+            train_data.filepaths, train_data.labels = unseen_imgs + seen_imgs, unseen_labs + seen_labs
+        train_data.label_id = True
+        return train_data
+
+    def row_weights(self, labels, names):
+        """FPL loss as per-row weights (steps.fpl_row_weights); plain strategies use the mean CE."""
+        if not getattr(self, "fpl", False) or self.paradigm == "ul":
+            return steps.fpl_row_weights([False] * len(labels))
+        if self.paradigm == "ssl":     # membership by file name (textual_fpl.py:123-165)
+            return steps.fpl_row_weights([n in self.check_unlabeled for n in names], gamma_seen=self.balance_param, gamma_pseudo=1.0)
+        unseen_ids = {self.label_to_idx[c] for c in self.unseen_classes}   # membership by label id (transductive_zsl/textual_fpl.py:117-147)
+        return steps.fpl_row_weights([int(l) in unseen_ids for l in labels], gamma_seen=1.0, gamma_pseudo=self.balance_param)
+
+    # ------------------------------------------------------------------ loops
+    def _loader(self, data, shuffle):
+        g = torch.Generator().manual_seed(0)
+        return torch.utils.data.DataLoader(data, batch_size=int(self.config.BATCH_SIZE), shuffle=shuffle, generator=g if shuffle else None)
+
+    def _class_space(self, only_seen):
+        classes = self.seen_classes if only_seen else self.classes
+        idx = torch.tensor([self.label_to_idx[c] for c in classes], device=self.device)
+        lut = torch.full((int(idx.max()) + 1,), -1, dtype=torch.long, device=self.device)
+        lut[idx] = torch.arange(len(classes), device=self.device)
+        return classes, idx, lut
+
+    def _train_epoch(self, train_loader, only_seen=False):
+        classes, ids, lut = self._class_space(only_seen)
+        accum = int(getattr(self.config, "ACCUMULATION_ITER", 1))
+        total, correct, count = 0.0, 0, 0
+        for i, (img, _, _, label, names) in enumerate(train_loader):
+            img, label = img.to(self.device), label.to(self.device)
+            image_features, text_features = self.features(img, classes)
+            logits = steps.CosineHeadFn.apply(image_features, text_features, self.scale())
+            w = self.row_weights(label.tolist(), names).to(self.device)
+            loss = steps.WeightedCEFn.apply(logits, lut[label], w) / accum
+            loss.backward()
+            total += float(loss.detach()) * accum
+            if (i + 1) % accum == 0 or i + 1 == len(train_loader):
+                gdist.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+                self.backpropagate()
+            correct += int((ids[logits.argmax(1)] == label).sum())
+            count += len(label)
+        self.update_scheduler()
+        return total / max(len(train_loader), 1), correct / max(count, 1)
+
+    @torch.no_grad()
+    def predict(self, data, classes):
+        """Global label ids predicted for every item of `data`, logits [N, len(classes)] on the CPU."""
+        ids = torch.tensor([self.label_to_idx[c] for c in classes], device=self.device)
+        outs = []
+        for batch in self._loader(data, False):
+            img = batch[0].to(self.device)
+            image_features, text_features = self.features(img, classes)
+            logits, _, am, _ = cosine_head(image_features, text_features, self.scale(), want_probs=False)
+            outs.append(logits)
+        logits = torch.cat(outs)
+        return ids[logits.argmax(1)].cpu(), logits.cpu()
+
+    def _run_validation(self, val_data, only_seen=False):
+        classes = self.seen_classes if only_seen and self.val_unseen_files is None else self.classes
+        pred, _ = self.predict(val_data, classes)
+        labels = torch.tensor([l if val_data.label_id else self.label_to_idx[l] for l in val_data.labels])
+        return float((pred == labels).float().mean())
+
+    def train(self, train_data, val_data, unlabeled_data=None, only_seen=False, iter_train=False):
+        train_data = self.create_training_dataset(train_data, unlabeled_data) if not iter_train else train_data
+        self.define_model(self.seen_classes if only_seen else self.classes)
+        loader = self._loader(train_data, True)
+        best_acc, best_prompt = -1.0, None
+        for epoch in range(int(self.config.EPOCHS)):
+            loss, acc = self._train_epoch(loader, only_seen=only_seen)
+            val_acc = self._run_validation(val_data, only_seen=only_seen) if val_data is not None and len(val_data) else acc
+            log.info(f"epoch {epoch}: loss {loss:.4f} train acc {acc:.3f} val acc {val_acc:.3f}")
+            if val_acc > best_acc:
+                best_acc, best_prompt = val_acc, self.prompt_snapshot()
+        return best_acc, best_prompt
+
+    # ------------------------------------------------------------------ evaluation
+    def test_predictions(self, data, standard_zsl=False):
+        import pandas as pd
+        classes = self.unseen_classes if standard_zsl else self.classes
+        pred, _ = self.predict(data, classes)
+        idx_to_class = {v: k for k, v in self.label_to_idx.items()}
+        df = pd.DataFrame({"id": [f.split("/")[-1] for f in data.filepaths], "class": [idx_to_class[int(p)] for p in pred]})
+        df.drop_duplicates(subset=["id", "class"], inplace=True)
+        return df
+
+    def evaluation(self, data):
+        pred, logits = self.predict(data, self.classes)
+        idx_to_class = {v: k for k, v in self.label_to_idx.items()}
+        return [f.split("/")[-1] for f in data.filepaths], [idx_to_class[int(p)] for p in pred], logits
+
+    # ------------------------------------------------------------------ pseudolabels from the trained model
+    @torch.no_grad()
+    def assign_pseudo_labels(self, k, unlabeled_data):
+        """The nine `assign_pseudo_labels` of the reference (e.g. transductive_zsl/multimodal_fpl.py:194-285):
+        leaderboard over the TRAINED model's logits on the unseen classes; text features are computed once per
+        call, not once per image."""
+        classes = self.unseen_classes if self.paradigm == "trzsl" else self.classes
+        feats_i, txt = [], None
+        for batch in self._loader(unlabeled_data, False):
+            image_features, text_features = self.features(batch[0].to(self.device), classes)
+            feats_i.append(image_features)
+            txt = text_features
+        fp, lab = pl.pseudolabel_from_features(torch.cat(feats_i), txt, self.scale(), list(unlabeled_data.filepaths),
+                                               [self.label_to_idx[c] for c in classes], k, argmax_on="logits")
+        unlabeled_data.filepaths, unlabeled_data.labels, unlabeled_data.label_id = fp, lab, True
+        return unlabeled_data
+
+    def get_pseudo_labels(self, unlabeled_examples):
+        return self.assign_pseudo_labels(int(self.config.N_PSEUDOSHOTS), unlabeled_examples)
+
+    # ------------------------------------------------------------------ iterative schedules
+    def _n_pseudoshots(self, niter, num_samples, n_unlabeled, n_classes):
+        n = int(niter * num_samples / n_classes)            # pseudo_iterative.py:62-75, 113-125
+        return n if n * n_classes <= n_unlabeled else math.floor(n_unlabeled / n_classes)
+
+    def grip_train(self, train_data, val_data, unlabeled_data, only_seen=False):
+        """GRIP: grow the number of pseudolabels per class by one STEP_QUANTILE of the pool per iteration,
+        re-initialising the prompts each time; iteration 1 labels with frozen CLIP, later ones with the
+        previously trained prompts."""
+        c = self.config
+        num_iter = int(100 / int(c.STEP_QUANTILE))
+        n_cls = len(self.unseen_classes if self.paradigm == "trzsl" else self.classes)
+        num_samples = int(len(unlabeled_data) / num_iter)
+        original_train, original_unlabeled = copy.copy(train_data.filepaths), copy.copy(unlabeled_data.filepaths)
+        original_labels, original_label_id = copy.copy(train_data.labels), train_data.label_id
+        out = None
+        for niter in range(1, num_iter + 1):
+            c.N_PSEUDOSHOTS = max(1, self._n_pseudoshots(niter, num_samples, len(original_unlabeled), n_cls))
+            train_data.filepaths, train_data.labels, train_data.label_id = list(original_train), list(original_labels), original_label_id
+            unlabeled_data.filepaths, unlabeled_data.labels = list(original_unlabeled), None
+            if niter == 1:
+                data = self.create_training_dataset(train_data, unlabeled_data)
+            else:
+                data = self.merge_pseudolabels(train_data, self.get_pseudo_labels(unlabeled_data))
+            out = self.train(data, val_data, only_seen=only_seen, iter_train=True)
+            log.info(f"GRIP iteration {niter}/{num_iter}: {c.N_PSEUDOSHOTS} pseudo-shots per class, val acc {out[0]:.3f}")
+        return out
+
+    def fixed_iterative_train(self, train_data, val_data, unlabeled_data, only_seen=False):
+        """Iterative FPL: same loop with a FIXED number of pseudo-shots per class."""
+        c = self.config
+        k = int(c.N_PSEUDOSHOTS)
+        original_train, original_unlabeled = copy.copy(train_data.filepaths), copy.copy(unlabeled_data.filepaths)
+        original_labels, original_label_id = copy.copy(train_data.labels), train_data.label_id
+        out = None
+        for niter in range(1, int(100 / int(c.STEP_QUANTILE)) + 1):
+            c.N_PSEUDOSHOTS = k
+            train_data.filepaths, train_data.labels, train_data.label_id = list(original_train), list(original_labels), original_label_id
+            unlabeled_data.filepaths, unlabeled_data.labels = list(original_unlabeled), None
+            data = self.create_training_dataset(train_data, unlabeled_data) if niter == 1 else \
+                self.merge_pseudolabels(train_data, self.get_pseudo_labels(unlabeled_data))
+            out = self.train(data, val_data, only_seen=only_seen, iter_train=True)
+        return out

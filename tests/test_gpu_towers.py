@@ -86,7 +86,7 @@ def test_golden_vitb16(models, golden_vitb16):
     assert (probs - torch.from_numpy(g["g3.zs_probs"])).abs().max().item() <= 5e-3
 
 
-@pytest.mark.parametrize("name,B,P", [("tiny", 37, 0), ("small", 9, 4), ("small", 130, 16)])
+@pytest.mark.parametrize("name,B,P", [("tiny", 37, 0), ("small", 9, 4), ("small", 130, 16), ("tinyL336", 3, 0), ("tinyL336", 2, 16)])
 def test_vision_vs_oracle_fresh_inputs(models, name, B, P):
     """Odd batch sizes (ragged GEMM tails) against the CPU oracle run here on the same inputs."""
     from conftest import oracle_clip
