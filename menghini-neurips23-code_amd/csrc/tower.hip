@@ -201,8 +201,7 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     if (D.kind == 0) {
         const int64_t G2 = D.seq0 - 1;
         const int64_t prow = round_up64(batch * G2, 256);
-        GRIP_REQUIRE(prow * t->L.kpad <= w.Mp * 4 * d, "internal: patch buffer does not fit its alias");
-        w.patches = w.h;
+        w.patches = prow * t->L.kpad <= w.Mp * 4 * d ? w.h : (half_t*)take(prow * t->L.kpad * 2);   // alias of h when it fits
         w.patch_out = (float*)take(batch * G2 * d * 4);
     }
     if (train) {
