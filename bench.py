@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pool", type=int, default=50000, help="images per GPU (weak scaling)")
-    ap.add_argument("--chunk", type=int, default=220, help="images per encode launch: 220 x 197 rows = 170 M-tiles of 256, i.e. a near-multiple-of-256-CUs tile count for every projection")
+    ap.add_argument("--chunk", type=int, default=440, help="images per encode launch: 440 x 197 rows = 339 M-tiles of 256, i.e. a near-multiple-of-256-CUs tile count for every projection")
     ap.add_argument("--classes", type=int, default=102)
     ap.add_argument("--prefix", type=int, default=16)
     ap.add_argument("--k", type=int, default=16)
