@@ -219,7 +219,7 @@ def main():
         return
     def kname(slot):
         v, e = divmod(slot, 8)
-        return {1: f"gemm_f16_kernel<{e}>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e]}]"
+        return {1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e]}]"
     dom = int(np.argmax(ms))
     achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     images = loop.n_total * args.steps

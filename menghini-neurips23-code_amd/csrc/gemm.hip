@@ -114,9 +114,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[RO
         epilogue_rows_impl<EPI, ROWFRAGS, true>(g, acc, slab, row0, col0, lane);
 }
 
-template <int EPI>
+// WMF = 16-row fragments per wave along M: 4 -> 128x128 block tile, 2 -> 64x128 (small-M problems such as the
+// training batches, where 128-row tiles leave half of the 256 CUs without a workgroup).
+template <int EPI, int WMF>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) half_t lds[2 * STAGE_HALFS];
+    constexpr int BMT = 2 * WMF * 16;
+    constexpr int STAGE = (BMT + BN) * BK;
+    constexpr int GA = BMT / 32;                 // global_load_lds per wave per tile for A (8 rows each)
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * STAGE];
 
     // ---- XCD-aware, bijective tile remap (block b runs on XCD b % 8)
     const int nwg = tiles_m * tiles_n;
@@ -126,32 +131,33 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
-    // ---- staging addresses: wave w fills rows [w*32, w*32+32) of the A tile and of the W tile,
-    // 8 rows (1 KiB) per instruction; lane l -> row l>>3, LDS chunk l&7, source chunk (l&7)^(l>>3).
+    // ---- staging addresses: wave w fills rows [w*BMT/4, +BMT/4) of the A tile and rows [w*32, +32) of the W
+    // tile, 8 rows (1 KiB) per instruction; lane l -> row l>>3, LDS chunk l&7, source chunk (l&7)^(l>>3).
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
-    const half_t* a_src = g.A + (size_t)(m0 + wave * 32 + srow) * K + schunk * 8;
+    const half_t* a_src = g.A + (size_t)(m0 + wave * (BMT / 4) + srow) * K + schunk * 8;
     const half_t* w_src = g.W + (size_t)(n0 + wave * 32 + srow) * K + schunk * 8;
 
     auto stage = [&](int buf, int kt) {
-        half_t* base = lds + buf * STAGE_HALFS + wave * 32 * BK;
+        half_t* abase = lds + buf * STAGE + wave * (BMT / 4) * BK;
+        half_t* bbase = lds + buf * STAGE + BMT * BK + wave * 32 * BK;
         const half_t* as = a_src + (size_t)kt * BK;
         const half_t* ws = w_src + (size_t)kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 8 * K), (AS3 void*)(base + i * 8 * BK), 16, 0, 0);
+        for (int i = 0; i < GA; ++i) {
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 8 * K), (AS3 void*)(abase + i * 8 * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 8 * K), (AS3 void*)(base + BM * BK + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 8 * K), (AS3 void*)(bbase + i * 8 * BK), 16, 0, 0);
         }
     };
 
@@ -162,13 +168,13 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
-        a_off[kk] = (wr * 64 + frow) * BK + chunk * 8;
-        b_off[kk] = BM * BK + (wc * 64 + frow) * BK + chunk * 8;
+        a_off[kk] = (wr * WMF * 16 + frow) * BK + chunk * 8;
+        b_off[kk] = BMT * BK + (wc * 64 + frow) * BK + chunk * 8;
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[WMF][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WMF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -178,16 +184,16 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
         const int buf = kt & 1;
         __syncthreads();  // waits vmcnt(0) for this wave's LDS-DMA, then barrier: tile kt visible, tile kt-1 fully read
         if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const half_t* st = lds + buf * STAGE_HALFS;
+        const half_t* st = lds + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            half8 af[4], bf[4];
+            half8 af[WMF], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+            for (int i = 0; i < WMF; ++i) af[i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < WMF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
     }
 
     __syncthreads();   // every wave is done with the stage buffers: reuse them as epilogue slabs
-    epilogue_rows<EPI, 4>(g, acc, (float*)lds + wave * EPI_SLAB_FLOATS, m0 + wr * 64, n0 + wc * 64, lane);
+    epilogue_rows<EPI, WMF>(g, acc, (float*)lds + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -493,7 +499,7 @@ static int launch_big(int epi, const GemmArgs& a, hipStream_t s) {
     return GRIP_OK;
 }
 
-// variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage), 3 = 256x128x32 (3-stage)
+// variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage), 3 = 256x128x32 (3-stage), 4 = 64x128x64 (2-stage)
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
@@ -507,6 +513,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
         const int64_t tm128 = (a.M + 127) / 128, tm256 = m256 / 256;
         double best = 0.85 * fill(tm128 * (a.N / 128), 512);
         variant = 1;
+        {
+            const double s4 = 0.70 * fill((int64_t)((a.M + 63) / 64) * (a.N / 128), 768);   // three 48-KiB workgroups per CU
+            if (s4 > best) { best = s4; variant = 4; }
+        }
         if (can_big) {
             const double s3 = 0.93 * fill(tm256 * (a.N / 128), 512);
             if (s3 > best) { best = s3; variant = 3; }
@@ -525,10 +535,14 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
         GRIP_REQUIRE(can_big, "gemm: 256x128 tile needs A padded to 256 rows");
         return launch_big<256, 128, 3>(epi, a, s);
     }
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
+    const int bmt = variant == 4 ? 64 : 128;
+    const int tiles_m = (a.M + bmt - 1) / bmt, tiles_n = a.N / BN;
     dim3 grid(tiles_m * tiles_n), block(256);
-#define GRIP_GEMM_CASE(E) \
-    case E: hipLaunchKernelGGL(gemm_f16_kernel<E>, grid, block, 0, s, a, tiles_m, tiles_n); break;
+#define GRIP_GEMM_CASE(E)                                                                                  \
+    case E:                                                                                                \
+        if (variant == 4) hipLaunchKernelGGL((gemm_f16_kernel<E, 2>), grid, block, 0, s, a, tiles_m, tiles_n); \
+        else hipLaunchKernelGGL((gemm_f16_kernel<E, 4>), grid, block, 0, s, a, tiles_m, tiles_n);          \
+        break;
     switch (epi) {
         GRIP_GEMM_CASE(EPI_F32)
         GRIP_GEMM_CASE(EPI_BIAS_F16)

@@ -28,7 +28,7 @@ def quick_gelu(x):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (3408, 2304, 768), (77 * 5, 512, 2048), (16, 512, 768),
                                    (50432, 768, 768), (12700, 2304, 768), (25000, 768, 3072), (16500, 3072, 768), (50000, 512, 128)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_gemm_epilogues(M, N, K, variant):
     if variant == 2 and N % 256:
         pytest.skip("256x256 tile needs N % 256 == 0")

@@ -40,6 +40,10 @@ def run(M, N, K, epi, variant, reps=20):
 
 imgs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 M = imgs * 197
-for name, N, K, epi in [("qkv", 2304, 768, 1), ("out", 768, 768, 3), ("fc", 3072, 768, 2), ("proj", 768, 3072, 3), ("f32", 768, 768, 0)]:
-    r = [run(M, N, K, epi, v) for v in (1, 2, 3, 0)]
-    print(f"{name:5s} M={M} N={N} K={K}: " + " | ".join(f"{nm} {m:.3f} ms {t:.0f} TF/s" for nm, (m, t) in zip(("128x128", "256x256", "256x128", "auto"), r)), flush=True)
+shapes = [("qkv", 2304, 768, 1), ("out", 768, 768, 3), ("fc", 3072, 768, 2), ("proj", 768, 3072, 3), ("f32", 768, 768, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "text":
+    M = imgs * 77
+    shapes = [("qkv", 1536, 512, 1), ("out", 512, 512, 3), ("fc", 2048, 512, 2), ("proj", 512, 2048, 3), ("dln", 512, 1536, 0)]
+for name, N, K, epi in shapes:
+    r = [run(M, N, K, epi, v) for v in (1, 2, 3, 4, 0)]
+    print(f"{name:5s} M={M} N={N} K={K}: " + " | ".join(f"{nm} {m:.3f} ms {t:.0f} TF/s" for nm, (m, t) in zip(("128x128", "256x256", "256x128", "64x128", "auto"), r)), flush=True)
