@@ -186,7 +186,7 @@ def main():
     rank, ws = gdist.init_from_env()
     if ws != args.gpus and not (ws == 1 and args.gpus == 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = gdist.local_device_index()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     lib = native.lib()
@@ -204,7 +204,7 @@ def main():
     gdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (ws > 1 and torch.distributed.get_backend() == "gloo") else device)
     if ws > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = el.item()

@@ -28,11 +28,21 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        backend = os.environ.get("GRIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_device_index())
     dist.init_process_group(backend=backend)
     return world()
+
+
+def local_device_index():
+    """GPU of this rank: LOCAL_RANK, or 0 for every rank when GRIP_SINGLE_DEVICE=1 (several ranks sharing one GPU
+    over gloo: how the N > 1 path is exercised on a one-GPU box)."""
+    return 0 if os.environ.get("GRIP_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _via_host():
+    return dist.get_backend() == "gloo"
 
 
 def shard_range(n, rank=None, world_size=None):
@@ -56,6 +66,10 @@ def allgather_rows(local, n_total, per):
         pad = torch.zeros(per, e, dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
         local = pad
+    if _via_host() and local.is_cuda:          # gloo moves host memory only
+        host = torch.empty(ws * per, e, dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu().contiguous())
+        return host[:n_total].to(local.device)
     out = torch.empty(ws * per, e, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out[:n_total]
@@ -67,7 +81,12 @@ def allreduce_mean_(tensors):
     if ws == 1 or not tensors:
         return
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat)
+    if _via_host() and flat.is_cuda:
+        h = flat.cpu()
+        dist.all_reduce(h)
+        flat = h.to(flat.device)
+    else:
+        dist.all_reduce(flat)
     flat /= ws
     off = 0
     for t in tensors:
