@@ -28,6 +28,16 @@ def fpl_row_weights(is_pseudo, gamma_seen=1.0, gamma_pseudo=1.0):
     return w
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def _finish(loss, params, optimizer):
     loss.backward()
     gdist.allreduce_mean_([p.grad for p in params if p.grad is not None])
@@ -39,10 +49,18 @@ def _finish(loss, params, optimizer):
 def coop_step(model, clip_model, images, labels, row_weight, optimizer, image_features=None):
     """Textual prompt step: text tower forward+backward over all class prompts, frozen image tower
     forward only (or cached features)."""
-    text_features = model(model.classes)
+    side = None
     if image_features is None:
-        with torch.no_grad():
+        # the frozen image tower does not depend on the prompt: run it on a second stream next to the text
+        # tower's forward (both are small-batch launches that leave CUs idle on their own)
+        side = _side_stream(images.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
             image_features = clip_model.encode_image(images)
+    text_features = model(model.classes)
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        image_features.record_stream(torch.cuda.current_stream())
     logits = CosineHeadFn.apply(image_features, text_features, clip_model.logit_scale.exp().item())
     loss = WeightedCEFn.apply(logits, labels, row_weight)
     return _finish(loss, [model.prefix], optimizer)
