@@ -16,6 +16,7 @@ import yaml
 
 from .. import config as gcfg, rng
 from ..data import ImagePool, TensorPoolDataset
+from ..utils import save_parameters, save_predictions
 from . import strategies as S
 
 log = logging.getLogger(__name__)
@@ -101,11 +102,14 @@ def workflow(obj_conf, device, n_synth, n_classes=10):
         val_acc, prompt = model.train(train_data, val_data, unlabeled_data if fpl else None, only_seen=only_seen)
     else:
         val_acc, prompt = getattr(model, method)(train_data, val_data, unlabeled_data, only_seen=only_seen)
+    save_parameters(prompt, obj_conf)                      # methods/main_SSL.py:400
     df = model.test_predictions(test_data, standard_zsl=False)
     truth = {files[i]: names[i] for i in test_ids}
     acc = float(np.mean([truth[i] == c for i, c in zip(df["id"], df["class"])]))
     result = {"model": obj_conf.MODEL, "paradigm": paradigm, "encoder": obj_conf.VIS_ENCODER, "val_accuracy": val_acc, "test_accuracy": acc,
               "n_train": len(train_data), "n_unlabeled": len(unlabeled), "n_test": len(test_ids)}
+    images_e, preds_e, logits_e = model.evaluation(test_data)   # methods/main_SSL.py:418-427
+    save_predictions({"images": images_e, "predictions": preds_e, "labels": [truth[i] for i in images_e], "logits": logits_e}, obj_conf)
     if paradigm == "trzsl":
         s = [truth[i] == c for i, c in zip(df["id"], df["class"]) if truth[i] in seen]
         u = [truth[i] == c for i, c in zip(df["id"], df["class"]) if truth[i] in unseen]

@@ -309,6 +309,9 @@ class TrainingStrategy:
             else:
                 data = self.merge_pseudolabels(train_data, self.get_pseudo_labels(unlabeled_data))
             out = self.train(data, val_data, only_seen=only_seen, iter_train=True)
+            from ..utils import save_parameters, save_pseudo_labels
+            save_pseudo_labels(list(data.filepaths), list(data.labels), c, niter)     # compute_metrics.py:150-154
+            save_parameters(out[1], c, iteration=niter)
             log.info(f"GRIP iteration {niter}/{num_iter}: {c.N_PSEUDOSHOTS} pseudo-shots per class, val acc {out[0]:.3f}")
         return out
 

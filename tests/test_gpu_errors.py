@@ -1,0 +1,82 @@
+"""Error behaviour of the C ABI on the GPU box: every misuse returns a status + message (no crash, no C++
+exception across the boundary), mirroring the reference's plain Python exceptions with GripError."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    return clip.load("tiny", device="cuda")[0]
+
+
+def test_workspace_too_small_and_misaligned(model):
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    from grip_amd.engine import _ptr, _stream
+    t = model.visual.tower
+    x = torch.randn(2, 3, 32, 32, device="cuda")
+    out = torch.empty(2, 128, device="cuda")
+    ws = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    rc = t.lib.grip_vit_forward(t.handle, _ptr(x), 0, None, 0, 2, _ptr(out), ctypes.c_void_p(ws.data_ptr()), 4096, 0, _stream())
+    assert rc == 3 and b"workspace too small" in t.lib.grip_last_error()
+    big = t.workspace(2, 0, False)
+    p, n = t._aligned(big)
+    rc = t.lib.grip_vit_forward(t.handle, _ptr(x), 0, None, 0, 2, _ptr(out), ctypes.c_void_p(p.value + 8), n - 8, 0, _stream())
+    assert rc == 1 and b"aligned" in t.lib.grip_last_error()
+    with pytest.raises(native.GripError):
+        native.check(rc)
+
+
+def test_backward_without_training_forward(model):
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    t = model.visual.tower
+    prefix = torch.randn(3, 128, device="cuda") * 0.02
+    x = torch.randn(2, 3, 32, 32, device="cuda")
+    _, ws = t.vit_forward(x, prefix, train=False)
+    with pytest.raises(native.GripError, match="train-mode forward"):
+        t.vit_backward(torch.ones(2, 128, device="cuda"), prefix, ws)
+
+
+def test_bad_arguments_are_rejected(model):
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    t = model.visual.tower
+    x = torch.randn(2, 3, 32, 32, device="cuda")
+    with pytest.raises(native.GripError, match="max_prefix"):
+        t.vit_forward(x, torch.zeros(100, 128, device="cuda"))            # more prompt tokens than the tower was built for
+    tt = model.text_tower
+    ids = torch.zeros(3, 77, dtype=torch.int32)
+    ids[:, 0], ids[:, 1] = 49406, 49407
+    with pytest.raises(native.GripError, match="prefix_classes"):
+        tt.text_forward(ids.cuda(), torch.zeros(2, 4, 128, device="cuda"))  # prefix for 2 classes, 3 prompts
+    with pytest.raises(native.GripError, match="not a vision tower"):
+        native.check(tt.lib.grip_vit_forward(tt.handle, None, 0, None, 0, 1, None, None, 0, 0, None))
+    with pytest.raises(NotImplementedError):
+        from grip_amd.models import CustomImageEncoder
+        CustomImageEncoder(model.visual)(x, torch.zeros(2, 128, device="cuda"), deep_embds=torch.zeros(1))
+
+
+def test_out_of_range_token_ids_do_not_fault(model):
+    ids = torch.full((2, 77), 10 ** 6, dtype=torch.int32)
+    ids[:, 0] = -5
+    out = model.encode_text(ids.cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+
+
+def test_head_and_leaderboard_argument_checks():
+    import numpy as np
+
+    import grip_amd  # noqa: F401
+    from grip_amd import engine, native
+    with pytest.raises(native.GripError, match="unsupported shape"):
+        engine.cosine_head(torch.zeros(4, 6, device="cuda"), torch.zeros(3, 6, device="cuda"), 1.0)   # e % 4 != 0
+    with pytest.raises(native.GripError, match="out of range"):
+        engine.leaderboard_scan(np.ones((2, 3), np.float32) / 3, np.array([0, 7]), np.array([0, 1]), 2)

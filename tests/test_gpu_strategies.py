@@ -66,3 +66,13 @@ def test_run_main_entry_point(tmp_path):
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["paradigm"] == "ul" and res["model"] == "textual_fpl"
     assert os.path.exists(tmp_path / "results" / "results_model_textual_fpl.json")
+    # on-disk artefacts with the reference's schemas (utils/compute_metrics.py:105-171, clip_pseudolabels.py:114)
+    import glob
+    import pickle
+    (pp,) = glob.glob(str(tmp_path / "trained_prompts" / "*.pickle"))
+    prompts = pickle.load(open(pp, "rb"))
+    assert isinstance(prompts, list) and prompts[0].shape == (1, 16, 256)
+    (ev,) = glob.glob(str(tmp_path / "evaluation" / "*.pickle"))
+    assert set(pickle.load(open(ev, "rb"))) == {"images", "predictions", "labels", "logits"}
+    (pl,) = glob.glob(str(tmp_path / "pseudolabels" / "*.pickle"))
+    assert set(pickle.load(open(pl, "rb"))) == {"filepaths", "labels"}
