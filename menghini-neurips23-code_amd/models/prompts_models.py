@@ -10,6 +10,16 @@ from .. import clip
 log = logging.getLogger(__name__)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class _ModuleShim:
     """Reference callers reach `.module.classes` whenever torch.cuda.is_available() (DDP-wrapped
     model, e.g. methods/semi_supervised_learning/textual_prompt.py:94-97); PyTorch-ROCm reports
@@ -79,6 +89,19 @@ class UPTModel(_ModuleShim, nn.Module):
 
     def forward(self, x, classes):
         coop_embs, vpt_embs = self.mix()
+        if x.is_cuda:
+            # the two towers are independent until the head: the image tower (forward and, through autograd's
+            # stream tracking, its backward) runs on a side stream next to the text tower
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                visual_out = self.image_encoder(x, vpt_embs)
+            vpt_embs.record_stream(side)
+            text_out = self.text_encoder(coop_embs, classes)
+            main.wait_stream(side)
+            visual_out.record_stream(main)
+            return text_out, visual_out
         text_out = self.text_encoder(coop_embs, classes)
         visual_out = self.image_encoder(x, vpt_embs)
         return text_out, visual_out
