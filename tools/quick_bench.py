@@ -21,5 +21,5 @@ for B in [int(a) for a in (sys.argv[2:] or ["16", "64", "256", "512"])]:
         m.encode_image(x)
     torch.cuda.synchronize()
     dt = (time.time() - t) / n
-    gf = 35.13 if name == "ViT-B/16" else 0
+    gf = {"ViT-B/16": 35.13, "ViT-L/14@336px": 381.9, "ViT-L/14": 162.0, "ViT-B/32": 8.8}.get(name, 0)
     print(f"{name} B={B}: {dt * 1e3:.2f} ms  {B / dt:.0f} img/s  {B * gf / dt / 1e3:.1f} TFLOP/s", flush=True)
