@@ -53,7 +53,6 @@ struct GemmArgs {
     const half_t* A;    // [Mpad, K], lda = K; rows >= M may hold anything finite or not (never stored)
     const half_t* W;    // [N, K]
     int M, N, K;
-    int ablate;         // debug only (timing ablations, results wrong): bit0 = no global loads in the K loop, bit1 = no LDS fragment reads in the K loop
     int variant;        // 0 = let the launcher choose the tile shape; 1/2/3 force 128x128 / 256x256 / 256x128 (tests, tuning)
     int64_t m_pad;      // rows allocated for A (>= M); the 256-row tile is used only when m_pad covers it
     const float* bias;  // [N] or null

@@ -383,8 +383,7 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
 extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const float* resid,
                                const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream) {
     GemmArgs a{};
-    a.variant = variant & 0xff;
-    a.ablate = variant >> 8;
+    a.variant = variant;
     a.A = (const half_t*)A; a.W = (const half_t*)W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid;
     a.aux = (const half_t*)aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
     return launch_gemm(epi, a, (hipStream_t)stream);
