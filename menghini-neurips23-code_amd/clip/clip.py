@@ -19,20 +19,40 @@ def _word_id(w: str) -> int:
     return 1000 + h % 39000
 
 
+_TOKENIZER = None
+
+
+def _bpe():
+    """The real BPE tokenizer when its merges file is available ($CLIP_BPE_VOCAB), else None."""
+    global _TOKENIZER
+    if _TOKENIZER is None:
+        from . import simple_tokenizer as st
+        _TOKENIZER = st.SimpleTokenizer() if os.path.exists(st.default_bpe_path()) else False
+    return _TOKENIZER or None
+
+
 def tokenize(texts, context_length: int = 77, truncate: bool = False):
-    """[n, 77] int tensor [SOT, ids..., EOT, 0...].  STAND-IN word-hash tokenizer: the BPE
-    vocabulary file is not available offline; structure (SOT/EOT, "X" -> 343,
-    EOT = largest id) is what CustomTextEncoder relies on (models/clip_encoders.py:54-60,86-89)."""
+    """[n, 77] int tensor [SOT, ids..., EOT, 0...] (same contract as openai-CLIP's clip.tokenize).
+    With a merges file ($CLIP_BPE_VOCAB) this is byte-level BPE (clip/simple_tokenizer.py); without one --
+    the vocabulary does not exist offline -- it is a STAND-IN word-hash tokenizer that keeps
+    the structure CustomTextEncoder relies on (SOT/EOT, "X" -> 343, EOT = largest id;
+    models/clip_encoders.py:54-60,86-89)."""
     if isinstance(texts, str):
         texts = [texts]
+    tk = _bpe()
     out = torch.zeros(len(texts), context_length, dtype=torch.int)
     for i, t in enumerate(texts):
-        ids = [_cfg.SOT_TOKEN] + [_word_id(w) for w in _WORD.findall(t.lower())] + [_cfg.EOT_TOKEN]
+        if tk is not None:
+            ids = [tk.sot] + tk.encode(t) + [tk.eot]
+            eot = tk.eot
+        else:
+            ids = [_cfg.SOT_TOKEN] + [_word_id(w) for w in _WORD.findall(t.lower())] + [_cfg.EOT_TOKEN]
+            eot = _cfg.EOT_TOKEN
         if len(ids) > context_length:
             if not truncate:
                 raise RuntimeError(f"Input {t} is too long for context length {context_length}")
             ids = ids[:context_length]
-            ids[-1] = _cfg.EOT_TOKEN
+            ids[-1] = eot
         out[i, : len(ids)] = torch.tensor(ids, dtype=torch.int)
     return out
 
