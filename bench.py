@@ -36,7 +36,7 @@ MODEL = "ViT-B/16"
 F_IMG = 35.13e9          # algorithmic FLOPs per image, frozen ViT-B/16 forward
 F_TXT = 5.96e9           # per class prompt, text tower forward
 PEAK_F16_TFLOPS = 2500.0 # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
-EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID_F32", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE"]
+EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE"]
 
 
 def synth_tokens(C, P, seed=7):

@@ -12,8 +12,8 @@
  * void*); handles are not thread-safe (one per process / GPU); no hidden device allocation after
  * grip_tower_create.  Device pointers are plain pointers into HBM (torch tensors' data_ptr()).
  *
- * Dtypes: GEMM operands f16 (MFMA v_mfma_f32_16x16x32_f16, f32 accumulate); residual stream,
- * LayerNorm, softmax, head, embeddings and gradients f32.
+ * Dtypes: GEMM operands and the residual stream f16 (MFMA v_mfma_f32_16x16x32_f16, f32 accumulate, adds into the
+ * stream in f32); LayerNorm statistics, softmax, head, embeddings and gradients f32.
  */
 #ifndef GRIP_AMD_H
 #define GRIP_AMD_H

@@ -13,6 +13,11 @@ typedef half_t half4 __attribute__((ext_vector_type(4)));
 typedef half_t half2v __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Residual stream element type.  f16, as the reference's own GPU path keeps it (clip.load on a GPU converts the model to
+// f16): every add into it happens in f32 inside a GEMM epilogue and is rounded once; LayerNorm statistics are f32.
+// Halves the bytes of the HBM-bound LayerNorm kernels and of the out-proj / c_proj epilogues.
+typedef half_t resid_t;
+
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
 
@@ -43,7 +48,7 @@ enum GemmEpi {
     EPI_F32 = 0,             // out_f32 = acc
     EPI_BIAS_F16 = 1,        // out_f16 = acc + bias
     EPI_BIAS_GELU_F16 = 2,   // out_f16 = quickgelu(acc + bias); if out2 != null, out2_f16 = acc + bias (pre-activation)
-    EPI_BIAS_RESID_F32 = 3,  // out_f32 = resid + acc + bias
+    EPI_BIAS_RESID = 3,      // out_resid = resid + acc + bias   (residual stream, resid_t)
     EPI_F16 = 4,             // out_f16 = acc
     EPI_GELUGRAD_F16 = 5,    // out_f16 = acc * quickgelu'(aux_f16)       (backward of c_fc activation)
     EPI_F32_SCALE = 6,       // out_f32 = acc * scalar
@@ -56,7 +61,7 @@ struct GemmArgs {
     int variant;        // 0 = let the launcher choose the tile shape; 1/2/3 force 128x128 / 256x256 / 256x128 (tests, tuning)
     int64_t m_pad;      // rows allocated for A (>= M); the 256-row tile is used only when m_pad covers it
     const float* bias;  // [N] or null
-    const float* resid; // [M, ldc] f32 (EPI_BIAS_RESID_F32)
+    const resid_t* resid; // [M, ldc] residual stream (EPI_BIAS_RESID)
     const half_t* aux;  // [M, ldc] f16 (EPI_GELUGRAD_F16)
     void* out;          // [M, ldc] f16 or f32
     void* out2;         // optional second output
@@ -69,20 +74,21 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
 // row-wise kernels (rowops.hip)
 int launch_im2col(const void* images, int images_f16, half_t* out, int B, int R, int patch, int Kpad, hipStream_t s);
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, float* x, int B, int G2, int d, hipStream_t s);
-int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
-int launch_gather_ln_f16(const float* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
+                           const float* gamma, const float* beta, resid_t* x, int B, int G2, int d, hipStream_t s);
+int launch_layernorm_f16(const resid_t* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
+int launch_gather_ln_f16(const resid_t* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
                          half_t* out, int n_rows, int d, hipStream_t s);
 int launch_text_embed(const int32_t* token_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, float* x, int C, int T, int d, int vocab, hipStream_t s);
+                      int prefix_classes, resid_t* x, int C, int T, int d, int vocab, hipStream_t s);
 int launch_transpose_f16(const half_t* in, half_t* out, int rows, int cols, int ld_in, hipStream_t s);
 
 // attention (attention.hip): qkv [B*S, 3*D] f16 -> out [B*S, D] f16
 int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s);
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
 // backward row kernels (rowops_bwd.hip)
-int launch_ln_bwd_add(const float* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s);
-int launch_ln_bwd_scatter(const float* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
+int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
+int launch_ln_bwd_add(const resid_t* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s);
+int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
                           int n, int d, hipStream_t s);
 int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* gamma, const float* scale, float* grad, int B, int S, int P, int d, hipStream_t s);
 int launch_text_prefix_grad(const float* dx, const float* scale, float* grad, int C, int T, int P, int prefix_classes, int d, hipStream_t s);

@@ -42,7 +42,7 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 template <int EPI, int ROWFRAGS, bool CHECK>
 __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
     constexpr int NP = ROWFRAGS / 2;
-    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID_F32);
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID);
     const int frow = lane & 15, fgrp = lane >> 4;
     const int rr = lane >> 4, cc = (lane & 15) * 4;
     const int col = col0 + cc;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
     }
     // operand prefetch (residual / GELU' argument): all 8 row loads of a pass are issued together, and
     // the loads of pass p+1 go out before the stores of pass p, so no load ever queues behind a store.
-    f32x4 res[2][8];
+    half4 res[2][8];
     half4 aux[2][8];
     auto prefetch = [&](int p, int b) {
 #pragma unroll
@@ -62,18 +62,18 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
             int row = row0 + p * 32 + it * 4 + rr;
             row = row < g.M ? row : g.M - 1;
             const size_t o = (size_t)row * ldc + col;
-            if constexpr (EPI == EPI_BIAS_RESID_F32) res[b][it] = *(const f32x4*)(g.resid + o);
+            if constexpr (EPI == EPI_BIAS_RESID) res[b][it] = *(const half4*)(g.resid + o);
             if constexpr (EPI == EPI_GELUGRAD_F16) aux[b][it] = *(const half4*)(g.aux + o);
         }
     };
-    if constexpr (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_GELUGRAD_F16) prefetch(0, 0);
+    if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_GELUGRAD_F16) prefetch(0, 0);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (ii * 16 + frow) * EPI_LDW + j * 16 + fgrp * 4) = acc[2 * p + ii][j];
-        if constexpr (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_GELUGRAD_F16)
+        if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_GELUGRAD_F16)
             if (p + 1 < NP) prefetch(p + 1, (p + 1) & 1);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -88,8 +88,10 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                     *(f32x4*)((float*)g.out + o) = v;
                 } else if constexpr (EPI == EPI_F32_SCALE) {
                     *(f32x4*)((float*)g.out + o) = v * g.scalar;
-                } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
-                    *(f32x4*)((float*)g.out + o) = v + res[p & 1][it];
+                } else if constexpr (EPI == EPI_BIAS_RESID) {
+                    const half4 rh = res[p & 1][it];
+                    v += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_F16) {
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_BIAS_GELU_F16) {
@@ -488,7 +490,7 @@ static int launch_big(int epi, const GemmArgs& a, hipStream_t s) {
         GRIP_GEMM_CASE(EPI_F32)
         GRIP_GEMM_CASE(EPI_BIAS_F16)
         GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
-        GRIP_GEMM_CASE(EPI_BIAS_RESID_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
         GRIP_GEMM_CASE(EPI_F16)
         GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
         GRIP_GEMM_CASE(EPI_F32_SCALE)
@@ -547,7 +549,7 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
         GRIP_GEMM_CASE(EPI_F32)
         GRIP_GEMM_CASE(EPI_BIAS_F16)
         GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
-        GRIP_GEMM_CASE(EPI_BIAS_RESID_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
         GRIP_GEMM_CASE(EPI_F16)
         GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
         GRIP_GEMM_CASE(EPI_F32_SCALE)

@@ -14,6 +14,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ f32x4 load4(const float* p, int i) { return ((const f32x4*)p)[i]; }
+__device__ __forceinline__ f32x4 load4(const half_t* p, int i) {
+    const half4 h = ((const half4*)p)[i];
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void store4(float* p, int i, f32x4 v) { ((f32x4*)p)[i] = v; }
+__device__ __forceinline__ void store4(half_t* p, int i, f32x4 v) { ((half4*)p)[i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
+
 template <int NV>
 __device__ __forceinline__ void ln_normalize(f32x4 (&v)[NV], int lane, int d4, int d, float& mean, float& rstd) {
     float s = 0.f;
@@ -34,8 +42,8 @@ __device__ __forceinline__ void ln_normalize(f32x4 (&v)[NV], int lane, int d4, i
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over rows of x (f32) -> f16.  row_index == null: row r reads x[r]; else row r reads
 // x[r * row_stride + row_index[r]] (EOT gather); row_stride alone gathers x[r * row_stride] (CLS).
-template <int NV>
-__global__ __launch_bounds__(256) void ln_f16_kernel(const float* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
+template <int NV, typename XT>
+__global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      half_t* __restrict__ out, int n_rows, int d) {
     const int lane = threadIdx.x & 63;
@@ -43,11 +51,11 @@ __global__ __launch_bounds__(256) void ln_f16_kernel(const float* __restrict__ x
     if (row >= n_rows) return;
     const int d4 = d >> 2;
     size_t src = (size_t)row * row_stride + (row_index ? row_index[row] : 0);
-    const f32x4* xr = (const f32x4*)(x + src * d);
+    const XT* xr = x + src * d;
     f32x4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < d4) v[i] = xr[lane + 64 * i];
+        if (lane + 64 * i < d4) v[i] = load4(xr, lane + 64 * i);
     float mean, rstd;
     ln_normalize<NV>(v, lane, d4, d, mean, rstd);
     half4* o = (half4*)(out + (size_t)row * d);
@@ -74,15 +82,21 @@ __global__ __launch_bounds__(256) void ln_f16_kernel(const float* __restrict__ x
         }                                                                                      \
     } while (0)
 
-int launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s) {
-    DISPATCH_NV(d, hipLaunchKernelGGL(ln_f16_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, (const int32_t*)nullptr, 1, gamma, beta, out, M, d));
+int launch_layernorm_f16(const resid_t* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s) {
+    DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, resid_t>), dim3((M + 3) / 4), dim3(256), 0, s, x, (const int32_t*)nullptr, 1, gamma, beta, out, M, d));
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
 
-int launch_gather_ln_f16(const float* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
+int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s) {
+    DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, float>), dim3((M + 3) / 4), dim3(256), 0, s, x, (const int32_t*)nullptr, 1, gamma, beta, out, M, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+int launch_gather_ln_f16(const resid_t* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
                          half_t* out, int n_rows, int d, hipStream_t s) {
-    DISPATCH_NV(d, hipLaunchKernelGGL(ln_f16_kernel<NV>, dim3((n_rows + 3) / 4), dim3(256), 0, s, x, row_index, row_stride, gamma, beta, out, n_rows, d));
+    DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, resid_t>), dim3((n_rows + 3) / 4), dim3(256), 0, s, x, row_index, row_stride, gamma, beta, out, n_rows, d));
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
@@ -97,7 +111,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ prefix, int P,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* __restrict__ x, int B, int G2, int d) {
+                                                              resid_t* __restrict__ x, int B, int G2, int d) {
     const int lane = threadIdx.x & 63;
     const int S = 1 + P + G2;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -118,17 +132,17 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
         }
     float mean, rstd;
     ln_normalize<NV>(v, lane, d4, d, mean, rstd);
-    f32x4* o = (f32x4*)(x + (size_t)row * d);
+    resid_t* o = x + (size_t)row * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
             const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], bb = ((const f32x4*)beta)[lane + 64 * i];
-            o[lane + 64 * i] = (v[i] - mean) * rstd * g + bb;
+            store4(o, lane + 64 * i, (v[i] - mean) * rstd * g + bb);
         }
 }
 
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, float* x, int B, int G2, int d, hipStream_t s) {
+                           const float* gamma, const float* beta, resid_t* x, int B, int G2, int d, hipStream_t s) {
     const int rows = B * (1 + P + G2);
     DISPATCH_NV(d, hipLaunchKernelGGL(vit_assemble_ln_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, x, B, G2, d));
     GRIP_CHECK_HIP(hipGetLastError());
@@ -139,7 +153,7 @@ int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float
 // Text embedding (models/clip_encoders.py:63-74): x[c, t] = (1 <= t <= P ? prefix[c or 0, t-1] : tok_emb[ids[c, t]]) + pos[t]
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, const float* __restrict__ prefix, int P,
-                                                         int prefix_classes, float* __restrict__ x, int C, int T, int d, int vocab) {
+                                                         int prefix_classes, resid_t* __restrict__ x, int C, int T, int d, int vocab) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= C * T) return;
@@ -154,12 +168,12 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
         src = (const f32x4*)(tok_emb + (size_t)id * d);
     }
     const f32x4* pp = (const f32x4*)(pos + (size_t)t * d);
-    f32x4* o = (f32x4*)(x + (size_t)row * d);
-    for (int f = lane; f < d4; f += 64) o[f] = src[f] + pp[f];
+    resid_t* o = x + (size_t)row * d;
+    for (int f = lane; f < d4; f += 64) store4(o, f, src[f] + pp[f]);
 }
 
 int launch_text_embed(const int32_t* token_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, float* x, int C, int T, int d, int vocab, hipStream_t s) {
+                      int prefix_classes, resid_t* x, int C, int T, int d, int vocab, hipStream_t s) {
     GRIP_REQUIRE(d % 4 == 0, "text_embed: width %% 4 != 0");
     hipLaunchKernelGGL(text_embed_kernel, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, tok_emb, pos, prefix, P, prefix_classes, x, C, T, d, vocab);
     GRIP_CHECK_HIP(hipGetLastError());

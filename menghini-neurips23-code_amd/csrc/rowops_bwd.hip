@@ -15,14 +15,20 @@ __device__ __forceinline__ float wave_sum_b(float v) {
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
-template <int NV>
-__device__ __forceinline__ void ln_bwd_row(const f32x4* __restrict__ xr, const f32x4* __restrict__ dyr, const f32x4* __restrict__ gamma,
+__device__ __forceinline__ f32x4 load4b(const float* p, int i) { return ((const f32x4*)p)[i]; }
+__device__ __forceinline__ f32x4 load4b(const half_t* p, int i) {
+    const half4 h = ((const half4*)p)[i];
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+template <int NV, typename XT>
+__device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x4* __restrict__ dyr, const f32x4* __restrict__ gamma,
                                            int lane, int d4, int d, f32x4 (&dx)[NV]) {
     f32x4 x[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < d4) { x[i] = xr[lane + 64 * i]; s += x[i][0] + x[i][1] + x[i][2] + x[i][3]; }
+        if (lane + 64 * i < d4) { x[i] = load4b(xr, lane + 64 * i); s += x[i][0] + x[i][1] + x[i][2] + x[i][3]; }
     const float mean = wave_sum_b(s) / (float)d;
     float q = 0.f;
 #pragma unroll
@@ -47,14 +53,14 @@ __device__ __forceinline__ void ln_bwd_row(const f32x4* __restrict__ xr, const f
 
 // dx[r] += LNbwd(dln[r]; x[r]);  dxh[r] = f16(dx[r])            (r < M)
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_add_kernel(const float* __restrict__ x, const float* __restrict__ dln, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void ln_bwd_add_kernel(const resid_t* __restrict__ x, const float* __restrict__ dln, const float* __restrict__ gamma,
                                                          float* __restrict__ dx, half_t* __restrict__ dxh, int M, int d) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int d4 = d >> 2;
     f32x4 g[NV];
-    ln_bwd_row<NV>((const f32x4*)(x + (size_t)row * d), (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g);
+    ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g);
     f32x4* o = (f32x4*)(dx + (size_t)row * d);
     half4* oh = (half4*)(dxh + (size_t)row * d);
 #pragma unroll
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_bwd_add_kernel(const float* __restrict
 // Final LayerNorm (ln_post on the CLS row / ln_final on the EOT row): dx[row_b] = LNbwd(dy[b]; x[row_b]),
 // row_b = b * stride + (index ? index[b] : 0).  dx / dxh were zero-filled before.
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_scatter_kernel(const float* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ index,
+__global__ __launch_bounds__(256) void ln_bwd_scatter_kernel(const resid_t* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ index,
                                                              int stride, const float* __restrict__ gamma, float* __restrict__ dx,
                                                              half_t* __restrict__ dxh, int n, int d) {
     const int lane = threadIdx.x & 63;
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_bwd_scatter_kernel(const float* __rest
     const int d4 = d >> 2;
     const size_t row = (size_t)b * stride + (index ? index[b] : 0);
     f32x4 g[NV];
-    ln_bwd_row<NV>((const f32x4*)(x + row * d), (const f32x4*)(dy + (size_t)b * d), (const f32x4*)gamma, lane, d4, d, g);
+    ln_bwd_row<NV>(x + row * d, (const f32x4*)(dy + (size_t)b * d), (const f32x4*)gamma, lane, d4, d, g);
     f32x4* o = (f32x4*)(dx + row * d);
     half4* oh = (half4*)(dxh + row * d);
 #pragma unroll
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void vit_prefix_grad_kernel(const float* __res
     for (int i = 0; i < NV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < B; ++b) {
         f32x4 g[NV];
-        ln_bwd_row<NV>((const f32x4*)(prefix + (size_t)s * d), (const f32x4*)(dx + ((size_t)b * S + 1 + s) * d), (const f32x4*)gamma, lane, d4, d, g);
+        ln_bwd_row<NV>(prefix + (size_t)s * d, (const f32x4*)(dx + ((size_t)b * S + 1 + s) * d), (const f32x4*)gamma, lane, d4, d, g);
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (lane + 64 * i < d4) acc[i] += g[i];
@@ -179,12 +185,12 @@ __global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __re
         }                                                                                      \
     } while (0)
 
-int launch_ln_bwd_add(const float* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s) {
+int launch_ln_bwd_add(const resid_t* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s) {
     DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_add_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, dx, dxh, M, d));
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
-int launch_ln_bwd_scatter(const float* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
+int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
                           int n, int d, hipStream_t s) {
     DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_scatter_kernel<NV>, dim3((n + 3) / 4), dim3(256), 0, s, x, dy, index, stride, gamma, dx, dxh, n, d));
     GRIP_CHECK_HIP(hipGetLastError());

@@ -4,7 +4,7 @@
 // and CustomTextEncoder.forward (:43-90) of the reference, with the per-block arithmetic of the
 // published openai/CLIP ResidualAttentionBlock: x += out_proj(MHSA(ln_1 x)); x += c_proj(QuickGELU(c_fc(ln_2 x))).
 //
-// HBM layout: residual stream x f32 [B*S, d] row-major (token-major, so every GEMM sees one
+// HBM layout: residual stream x (resid_t = f16, accumulated in f32 inside the GEMM epilogues) [B*S, d] row-major (token-major, so every GEMM sees one
 // [M, K] x [N, K]^T problem over all images of the chunk); GEMM operands (LayerNorm output, packed
 // qkv [M, 3d], attention output, MLP hidden [M, 4d]) f16.  Row counts are padded to the 128-row GEMM
 // tile in the workspace; padding rows are never stored to and never read back.
@@ -143,7 +143,7 @@ extern "C" int grip_layout_size(const grip_dims* dims, int64_t* n_f16, int64_t* 
 struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, train) problem
     int batch = 0, P = 0, train = 0, S = 0, M = 0;
     int64_t Mp = 0;
-    float* x = nullptr;        // inference residual stream
+    resid_t* x = nullptr;      // inference residual stream
     half_t* xn = nullptr;
     half_t* qkv = nullptr;
     half_t* att = nullptr;
@@ -152,7 +152,7 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     half_t* patches = nullptr; // alias of h
     float* patch_out = nullptr;// alias of qkv
     // train-mode saves, one per layer (x_in has layers+1 entries)
-    std::vector<float*> x_in, x_mid;
+    std::vector<resid_t*> x_in, x_mid;
     std::vector<half_t*> qkv_l, att_l, hpre_l;
     // backward scratch
     float* dx = nullptr;
@@ -193,7 +193,7 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     const int64_t Bp = round_up64(batch, 256);
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return (void*)p; };
-    if (!train) w.x = (float*)take(w.Mp * d * 4);
+    if (!train) w.x = (resid_t*)take(w.Mp * d * sizeof(resid_t));
     w.xn = (half_t*)take(w.Mp * d * 2);
     if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * 2); w.att = (half_t*)take(w.Mp * d * 2); }
     w.h = (half_t*)take(w.Mp * 4 * d * 2);
@@ -208,9 +208,9 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
         const int Lc = D.layers;
         w.x_in.assign((size_t)Lc + 1, nullptr); w.x_mid.assign((size_t)Lc, nullptr);
         w.qkv_l.assign((size_t)Lc, nullptr); w.att_l.assign((size_t)Lc, nullptr); w.hpre_l.assign((size_t)Lc, nullptr);
-        for (int i = 0; i <= Lc; ++i) w.x_in[(size_t)i] = (float*)take(w.Mp * d * 4);
+        for (int i = 0; i <= Lc; ++i) w.x_in[(size_t)i] = (resid_t*)take(w.Mp * d * sizeof(resid_t));
         for (int i = 0; i < Lc; ++i) {
-            w.x_mid[(size_t)i] = (float*)take(w.Mp * d * 4);
+            w.x_mid[(size_t)i] = (resid_t*)take(w.Mp * d * sizeof(resid_t));
             w.qkv_l[(size_t)i] = (half_t*)take(w.Mp * 3 * d * 2);
             w.att_l[(size_t)i] = (half_t*)take(w.Mp * d * 2);
             w.hpre_l[(size_t)i] = (half_t*)take(w.Mp * 4 * d * 2);
@@ -278,17 +278,17 @@ extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix
 // ---------------------------------------------------------------------------------------------- forward
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-static int run_blocks(grip_tower* t, Workspace& w, float* x0, int causal, hipStream_t s, float** x_final) {
+static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipStream_t s, resid_t** x_final) {
     const int d = t->D.width, H = t->D.heads;
     const half_t* W = t->w16;
     const float* F = t->w32;
-    float* x = x0;
+    resid_t* x = x0;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
         half_t* qkv = w.train ? w.qkv_l[(size_t)l] : w.qkv;
         half_t* att = w.train ? w.att_l[(size_t)l] : w.att;
-        float* x_mid = w.train ? w.x_mid[(size_t)l] : x;
-        float* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
+        resid_t* x_mid = w.train ? w.x_mid[(size_t)l] : x;
+        resid_t* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
         RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, w.M, d, s));
         GemmArgs a{};
         a.A = w.xn; a.W = W + lw.in_w; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
@@ -296,7 +296,7 @@ static int run_blocks(grip_tower* t, Workspace& w, float* x0, int causal, hipStr
         RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
         a = GemmArgs{};
         a.A = att; a.W = W + lw.out_w; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
-        RUN(launch_gemm(EPI_BIAS_RESID_F32, a, s));
+        RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, w.M, d, s));
         a = GemmArgs{};
         a.A = w.xn; a.W = W + lw.fc_w; a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.h; a.ldc = 4 * d;
@@ -304,7 +304,7 @@ static int run_blocks(grip_tower* t, Workspace& w, float* x0, int causal, hipStr
         RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
         a = GemmArgs{};
         a.A = w.h; a.W = W + lw.proj_w; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
-        RUN(launch_gemm(EPI_BIAS_RESID_F32, a, s));
+        RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         x = x_out;
     }
     *x_final = x;
@@ -336,9 +336,9 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         GemmArgs a{};
         a.A = w.patches; a.W = W + t->L.conv_w; a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
-        float* x0 = train ? w.x_in[0] : w.x;
+        resid_t* x0 = train ? w.x_in[0] : w.x;
         RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, batch, G2, d, s));
-        float* xf = nullptr;
+        resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/0, s, &xf));
         RUN(launch_gather_ln_f16(xf, nullptr, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, batch, d, s));
         a = GemmArgs{};
@@ -363,9 +363,9 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         const int d = D.width;
         const half_t* W = t->w16;
         const float* F = t->w32;
-        float* x0 = train ? w.x_in[0] : w.x;
+        resid_t* x0 = train ? w.x_in[0] : w.x;
         RUN(launch_text_embed(token_ids, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, n_class, D.seq0, d, D.vocab, s));
-        float* xf = nullptr;
+        resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/1, s, &xf));
         RUN(launch_gather_ln_f16(xf, eot_index, D.seq0, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, n_class, d, s));
         GemmArgs a{};
@@ -380,11 +380,11 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
 // ---------------------------------------------------------------------------------------------- test hooks
 // Kernel-level entry points for the unit parity tests (tests/test_gpu_kernels.py).  Not part of the
 // drop-in ABI (not declared in include/grip_amd.h); they launch exactly the kernels the towers use.
-extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const float* resid,
+extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid,
                                const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream) {
     GemmArgs a{};
     a.variant = variant;
-    a.A = (const half_t*)A; a.W = (const half_t*)W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid;
+    a.A = (const half_t*)A; a.W = (const half_t*)W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = (const resid_t*)resid;
     a.aux = (const half_t*)aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
     return launch_gemm(epi, a, (hipStream_t)stream);
 }
@@ -392,7 +392,7 @@ extern "C" int grip_debug_attention(const void* qkv, void* out, int B, int S, in
     return launch_attention_fwd((const half_t*)qkv, (half_t*)out, B, S, H, causal, (hipStream_t)stream);
 }
 extern "C" int grip_debug_layernorm(const float* x, const float* gamma, const float* beta, void* out, int M, int d, void* stream) {
-    return launch_layernorm_f16(x, gamma, beta, (half_t*)out, M, d, (hipStream_t)stream);
+    return launch_layernorm_f16_from_f32(x, gamma, beta, (half_t*)out, M, d, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------- backward

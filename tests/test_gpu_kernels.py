@@ -59,12 +59,14 @@ def test_gemm_epilogues(M, N, K, variant):
     torch.testing.assert_close(out16.float(), quick_gelu(ref + bias), **tol)
     torch.testing.assert_close(pre.float(), ref + bias, **tol)
 
-    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), None, _p(out), None, 1.0, Mp, variant, _stream()))
-    torch.testing.assert_close(out, ref + bias + resid, rtol=1e-4, atol=1e-4)
+    # residual epilogue: the residual stream is f16 (added in f32, rounded once)
+    resid16 = resid.half()
+    native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid16), None, _p(out16), None, 1.0, Mp, variant, _stream()))
+    torch.testing.assert_close(out16.float(), ref + bias + resid16.float(), **tol)
     # in place (out aliases resid), as the inference path uses it
-    r2 = resid.clone()
+    r2 = resid16.clone()
     native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(r2), None, _p(r2), None, 1.0, Mp, variant, _stream()))
-    torch.testing.assert_close(r2, ref + bias + resid, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(r2.float(), ref + bias + resid16.float(), **tol)
 
     native.check(lib.grip_debug_gemm(5, _p(A), _p(W), M, N, K, None, None, _p(aux), _p(out16), None, 1.0, Mp, variant, _stream()))
     x = aux.float()

@@ -22,8 +22,8 @@ def run(M, N, K, epi, variant, reps=20):
     if __import__("os").environ.get("ZERO"):
         A.zero_(); W.zero_()
     bias = torch.randn(N, device="cuda")
-    resid = torch.randn(M, N, device="cuda")
-    out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi in (0, 3) else torch.float16)
+    resid = torch.randn(M, N, device="cuda").half()
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == 0 else torch.float16)
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     f = lambda: native.check(lib.grip_debug_gemm(epi, p(A), p(W), M, N, K, p(bias), p(resid), None, p(out), None, 1.0, Mp, variant, s))
     for _ in range(3):
