@@ -1,17 +1,20 @@
-// f16 MFMA GEMM for gfx950: C[M,N] = epi(A[M,K] * W[N,K]^T), f32 accumulate.
+// f16 MFMA GEMMs for gfx950: C[M,N] = epi(A[M,K] * W[N,K]^T), f32 accumulate, v_mfma_f32_16x16x32_f16.
 //
-// Block tile 128x128x64, 256 threads = 4 waves in a 2x2 grid, each wave a 64x64 sub-tile of
-// 4x4 v_mfma_f32_16x16x32_f16 fragments.  A and W tiles go HBM -> LDS with direct
-// global_load_lds (16 B per lane, 1 KiB per wave instruction, lane-linear LDS image); the 16-byte
-// chunk index is XOR-swizzled with (row & 7) on the SOURCE address and again on the ds_read_b128
-// address, which makes the fragment reads bank-conflict free (guide T2 / rule 21).  Two LDS
-// stages: the loads of tile t+1 are issued right after the barrier that publishes tile t and fly
-// under its 32 MFMAs per wave; one barrier per K tile.
-// The MFMA is issued with swapped operands (W fragment first) so each lane ends up with four
-// CONSECUTIVE output columns of one row: the epilogue reads bias / residual and writes C with
-// 8-byte (f16) or 16-byte (f32) accesses.
-// Workgroup ids are remapped so every XCD (private 4 MiB L2) owns a contiguous run of tiles,
-// N-fastest: the A row panel and the W panel stay L2-resident across the run.
+// Three kernels share one design (this header) and one epilogue:
+//   gemm_big_kernel<EPI,256,256,4>  large problems (the pool encode): 256x256x32 tile, 8 waves, 4-slot LDS ring,
+//                                   two wave groups in anti-phase                      -- see its own header below
+//   gemm_big_kernel<EPI,256,128,3>  same with 4 waves and two workgroups per CU (used where 256x256 tile counts
+//                                   quantise badly over the 256 CUs)
+//   gemm_f16_kernel<EPI,WMF>        small M (training batches): 128x128x64 or 64x128x64 tile, 4 waves in a 2x2 grid,
+//                                   two LDS stages, one barrier per K tile
+// Common to all: A and W tiles go HBM -> LDS with direct global_load_lds (16 B per lane, 1 KiB per wave instruction,
+// lane-linear LDS image); the 16-byte chunk index is XOR-swizzled on the SOURCE address and again on the
+// ds_read_b128 address, which makes the fragment reads bank-conflict free (guide T2 / rule 21).  The MFMA is issued with
+// swapped operands (W fragment first) so each lane ends up with four CONSECUTIVE output columns of one row; the
+// accumulators are then transposed through a wave-private LDS slab so that bias / residual / C move as whole 128-byte
+// lines (epilogue_rows).  Workgroup ids are remapped so every XCD (private 4 MiB L2) owns a contiguous run of tiles,
+// N-fastest: the A row panel and the W panel stay L2-resident across the run.  The launcher picks the tile shape by
+// (relative rate) x (fill of the last wave of workgroups).
 #include <type_traits>
 
 #include "common.h"

@@ -1,5 +1,5 @@
 // Row-wise, HBM-bound kernels of the CLIP towers: patch gather (im2col), sequence assembly with
-// prompt insertion + LayerNorm, LayerNorm f32 -> f16, CLS/EOT gather + LayerNorm, token-embedding
+// prompt insertion + LayerNorm, LayerNorm of the f16 residual stream (f32 statistics) -> f16 GEMM operand, CLS/EOT gather + LayerNorm, token-embedding
 // gather with prompt splice, f16 transpose.  One wave (64 lanes) owns one row of width d and keeps
 // it in registers as float4 chunks (lane l holds float4 index l + 64*i): every global access is a
 // 16-byte, fully coalesced access, statistics are two in-register passes + a 6-step xor reduction.
@@ -40,7 +40,7 @@ __device__ __forceinline__ void ln_normalize(f32x4 (&v)[NV], int lane, int d4, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm over rows of x (f32) -> f16.  row_index == null: row r reads x[r]; else row r reads
+// LayerNorm over rows of x (residual stream, f16; or f32 for the test hook) -> f16.  row_index == null: row r reads x[r]; else row r reads
 // x[r * row_stride + row_index[r]] (EOT gather); row_stride alone gathers x[r * row_stride] (CLS).
 template <int NV, typename XT>
 __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
@@ -106,7 +106,7 @@ int launch_gather_ln_f16(const resid_t* x, const int32_t* row_index, int row_str
 //   row (b, 0)            = class_embedding + pos[0]
 //   row (b, 1..P)         = prefix[s-1]                         (no positional embedding)
 //   row (b, 1+P+j)        = patch_out[b*G2 + j] + pos[1+j]
-// then LayerNorm -> x (f32 residual stream), S = 1 + P + G2.
+// then LayerNorm -> x (residual stream), S = 1 + P + G2.
 template <int NV>
 __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ prefix, int P,
