@@ -87,10 +87,7 @@ class Loop:
             txt = self.m.encode_text(self.zs_tokens)
             # every rank encodes its own pool; embeddings are gathered in global (rank-major) order
             local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
-            tower = self.m.visual.tower
-            for s in range(0, a.pool, a.chunk):
-                e = min(s + a.chunk, a.pool)
-                local[s:e] = tower.vit_forward(self.pool[s:e])[0]
+            self.m.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk, streams=a.streams)
             emb = gdist.allgather_rows(local, self.n_total, a.pool)
             logits, probs, am_l, am_p = engine.cosine_head(emb, txt, self.m.logit_scale.exp().item())
             probs_h = probs.cpu().numpy()
@@ -175,6 +172,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pool", type=int, default=50000, help="images per GPU (weak scaling)")
     ap.add_argument("--chunk", type=int, default=440, help="images per encode launch: 440 x 197 rows = 339 M-tiles of 256, i.e. a near-multiple-of-256-CUs tile count for every projection")
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
+                    help="1: every kernel on one stream, so the per-kernel HIP-event / rocprof durations behind the roofline block are exclusive; "
+                         "2: alternate encode chunks on two streams (what pseudolabels.encode_pool does by default; +6 %% images/s, per-kernel durations overlap)")
     ap.add_argument("--classes", type=int, default=102)
     ap.add_argument("--prefix", type=int, default=16)
     ap.add_argument("--k", type=int, default=16)
@@ -233,7 +233,7 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "Flowers102-shaped CoOp textual-prompt SSL pseudolabel+prompt-step loop, ViT-B/16 (BASELINE.json configs[1])",
                    "pool_images_per_gpu": args.pool, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
-                   "encode_chunk": args.chunk, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
+                   "encode_chunk": args.chunk, "encode_streams": args.streams, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
                    "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps)},
         "pseudolabel_images_per_sec": images / loop.t_pl if loop.t_pl else None,
         "train_images_per_sec": (loop.train_steps * args.batch * ws * args.steps) / loop.t_tr if loop.t_tr else None,

