@@ -250,11 +250,11 @@ static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_ou
 
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s) {
     const int kvc = (S + 31) / 32;
-    GRIP_REQUIRE(S >= 1 && kvc <= 8, "attention backward: sequence length %d unsupported (max 256 in this round)", S);
+    GRIP_REQUIRE(S >= 1 && kvc <= 9, "attention backward: sequence length %d unsupported (max 288: K, V and their transposes of one head must fit the 160 KiB LDS)", S);
 #define GRIP_ATTN(N)                                                                        \
     if (kvc <= N) return causal ? launch_bwd_one<N, true>(qkv, o, d_out, dqkv, B, S, H, s)  \
                                 : launch_bwd_one<N, false>(qkv, o, d_out, dqkv, B, S, H, s);
-    GRIP_ATTN(1) GRIP_ATTN(2) GRIP_ATTN(3) GRIP_ATTN(7) GRIP_ATTN(8)
+    GRIP_ATTN(1) GRIP_ATTN(2) GRIP_ATTN(3) GRIP_ATTN(4) GRIP_ATTN(5) GRIP_ATTN(6) GRIP_ATTN(7) GRIP_ATTN(8) GRIP_ATTN(9)
 #undef GRIP_ATTN
     return GRIP_ERR_ARG;
 }

@@ -37,7 +37,7 @@ def assert_grad_close(got, want, what, cos_tol=1e-3, rel_tol=3e-2):
     assert rel <= rel_tol, f"{what}: relative L2 error {rel:.3e}"
 
 
-@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (2, 40, 2, 1), (2, 77, 8, 1), (2, 197, 12, 0), (1, 213, 12, 0), (1, 250, 3, 0)])
+@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (2, 40, 2, 1), (2, 77, 8, 1), (2, 197, 12, 0), (1, 213, 12, 0), (1, 250, 3, 0), (1, 273, 4, 0), (2, 120, 2, 0), (1, 150, 2, 1)])
 def test_attention_backward(B, S, H, causal):
     import grip_amd  # noqa: F401
     from grip_amd import native
