@@ -73,7 +73,8 @@ class Loop:
         self.class_labels = list(range(self.C))
         prefix = torch.from_numpy(rng.normal(1, rng.stream_id("bench.prefix"), (1, self.P, self.d.transformer_width), 0.0, 0.02)).to(device)
         enc = CustomTextEncoder(self.m, device, torch.float32)
-        enc._tok_cache[(self.P, tuple(self.classes))] = synth_tokens(self.C, self.P).to(device)   # no tokenizer needed
+        self.coop_tokens = synth_tokens(self.C, self.P).to(device)
+        enc._tok_cache[(self.P, tuple(self.classes))] = self.coop_tokens   # no tokenizer needed
         self.model = TextPrefixModel(prefix, enc, self.classes, device=device)
         self.opt = torch.optim.SGD([self.model.prefix], lr=0.1, weight_decay=0.1)
         self.t_pl = self.t_tr = 0.0
@@ -234,7 +235,8 @@ def main():
         "config": {"workload": "Flowers102-shaped CoOp textual-prompt SSL pseudolabel+prompt-step loop, ViT-B/16 (BASELINE.json configs[1])",
                    "pool_images_per_gpu": args.pool, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
                    "encode_chunk": args.chunk, "encode_streams": args.streams, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
-                   "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps)},
+                   "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps),
+                   "text_positions_encoded": int(getattr(loop.coop_tokens, "_grip_seq_len", 77) or 77)},
         "pseudolabel_images_per_sec": images / loop.t_pl if loop.t_pl else None,
         "train_images_per_sec": (loop.train_steps * args.batch * ws * args.steps) / loop.t_tr if loop.t_tr else None,
         "algorithmic_tflops": (images * F_IMG + args.steps * args.classes * F_TXT

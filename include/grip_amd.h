@@ -36,7 +36,7 @@ typedef enum {
 const char* grip_last_error(void);
 /* ABI version of this header; the host layer refuses a library that reports another one. */
 int grip_abi_version(void);
-#define GRIP_ABI_VERSION 1
+#define GRIP_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------
  * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
@@ -85,8 +85,9 @@ int grip_tower_finalize(grip_tower* t, void* stream);
 int grip_tower_destroy(grip_tower* t);
 
 /* Workspace bytes for a forward over `batch` units (images, or class prompts for the text tower)
- * with `n_prefix` prompt tokens.  train != 0 keeps the activations backward needs. */
-int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int train, size_t* bytes);
+ * with `n_prefix` prompt tokens.  seq_len: text tower only, see grip_text_forward (0 = full context; pass 0 for the
+ * vision tower).  train != 0 keeps the activations backward needs. */
+int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int seq_len, int train, size_t* bytes);
 
 /* ------------------------------------------------------------------------------------------
  * CustomVisionTransformer.forward(x, image_prefix) / clip_model.encode_image(x)
@@ -109,10 +110,14 @@ int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* 
  * (models/clip_encoders.py:43-90; :13-22 with n_prefix = 0).  Tokenisation stays on the host.
  *   token_ids  [n_class, seq0] int32 device; eot_index [n_class] int32 device (= token_ids.argmax(-1))
  *   prefix     [prefix_classes, n_prefix, width] f32; prefix_classes is 1 (broadcast, CoOp) or n_class
+ *   seq_len    0 or seq0: encode all seq0 positions as the reference does.  0 < seq_len < seq0: encode only the first
+ *              seq_len positions; must be > max(eot_index).  The text transformer is causal and only the EOT row is
+ *              read, so positions after the last EOT cannot influence any output: the result is the same, the work
+ *              shrinks by seq0 / seq_len (CoOp prompts are ~20 of 77 tokens).
  *   out_emb    [n_class, embed_dim] f32
  */
 int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
-                      int n_prefix, int prefix_classes, int n_class, float* out_emb,
+                      int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
                       void* workspace, size_t workspace_bytes, int train, void* stream);
 
 /* grad_emb [n_class, embed_dim] -> grad_prefix [prefix_classes, n_prefix, width] (summed over classes

@@ -78,7 +78,7 @@ int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float
 int launch_layernorm_f16(const resid_t* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
 int launch_gather_ln_f16(const resid_t* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
                          half_t* out, int n_rows, int d, hipStream_t s);
-int launch_text_embed(const int32_t* token_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
+int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
                       int prefix_classes, resid_t* x, int C, int T, int d, int vocab, hipStream_t s);
 int launch_transpose_f16(const half_t* in, half_t* out, int rows, int cols, int ld_in, hipStream_t s);
 

@@ -151,7 +151,7 @@ int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float
 
 // ------------------------------------------------------------------------------------------------
 // Text embedding (models/clip_encoders.py:63-74): x[c, t] = (1 <= t <= P ? prefix[c or 0, t-1] : tok_emb[ids[c, t]]) + pos[t]
-__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok_emb,
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, int ld_ids, const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, const float* __restrict__ prefix, int P,
                                                          int prefix_classes, resid_t* __restrict__ x, int C, int T, int d, int vocab) {
     const int lane = threadIdx.x & 63;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     if (t >= 1 && t <= P) {
         src = (const f32x4*)(prefix + ((size_t)(prefix_classes == 1 ? 0 : c) * P + (t - 1)) * d);
     } else {
-        int id = ids[row];
+        int id = ids[(size_t)c * ld_ids + t];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         src = (const f32x4*)(tok_emb + (size_t)id * d);
     }
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     for (int f = lane; f < d4; f += 64) store4(o, f, src[f] + pp[f]);
 }
 
-int launch_text_embed(const int32_t* token_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
+int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
                       int prefix_classes, resid_t* x, int C, int T, int d, int vocab, hipStream_t s) {
     GRIP_REQUIRE(d % 4 == 0, "text_embed: width %% 4 != 0");
-    hipLaunchKernelGGL(text_embed_kernel, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, tok_emb, pos, prefix, P, prefix_classes, x, C, T, d, vocab);
+    hipLaunchKernelGGL(text_embed_kernel, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, x, C, T, d, vocab);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -180,13 +180,14 @@ struct grip_tower {
     int last_prefix_classes = 0;
 };
 
-static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w) {
+static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w, int seq_len = 0) {
     const grip_dims& D = t->D;
     GRIP_REQUIRE(batch > 0 && P >= 0 && P <= D.max_prefix, "batch must be positive and 0 <= n_prefix <= max_prefix (batch=%d n_prefix=%d max=%d)", batch, P, D.max_prefix);
     const int64_t d = D.width;
     w.batch = batch; w.P = P; w.train = train;
-    w.S = D.kind == 0 ? D.seq0 + P : D.seq0;
-    GRIP_REQUIRE(D.kind == 0 || P < D.seq0 - 1, "text: n_prefix %d does not fit the context", P);
+    GRIP_REQUIRE(seq_len >= 0 && seq_len <= D.seq0 && (D.kind == 1 || seq_len == 0), "seq_len %d out of range", seq_len);
+    w.S = D.kind == 0 ? D.seq0 + P : (seq_len ? seq_len : D.seq0);
+    GRIP_REQUIRE(D.kind == 0 || P < w.S - 1, "text: n_prefix %d does not fit the sequence length %d", P, w.S);
     GRIP_REQUIRE(w.S <= 608, "sequence length %d exceeds the fused-attention limit 608", w.S);
     w.M = batch * w.S;
     w.Mp = round_up64(w.M, 256);
@@ -264,11 +265,11 @@ extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
     return GRIP_OK;
 }
 
-extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int train, size_t* bytes) {
+extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int seq_len, int train, size_t* bytes) {
     GRIP_REQUIRE(t && bytes, "workspace_bytes: null pointer");
     try {
         Workspace w;
-        int rc = carve(t, batch, n_prefix, train, nullptr, w);
+        int rc = carve(t, batch, n_prefix, train, nullptr, w, seq_len);
         if (rc) return rc;
         *bytes = w.bytes;
         return GRIP_OK;
@@ -311,10 +312,10 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipS
     return GRIP_OK;
 }
 
-static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t ws_bytes, Workspace& w) {
+static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t ws_bytes, Workspace& w, int seq_len = 0) {
     GRIP_REQUIRE(t && ws, "null tower / workspace");
     if (!t->finalized) { grip_set_error("tower not finalized: call grip_tower_finalize after filling the weight blobs"); return GRIP_ERR_STATE; }
-    RUN(carve(t, batch, P, train, (char*)ws, w));
+    RUN(carve(t, batch, P, train, (char*)ws, w, seq_len));
     if (w.bytes > ws_bytes) { grip_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes); return GRIP_ERR_WORKSPACE; }
     GRIP_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
     return GRIP_OK;
@@ -350,24 +351,24 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
 }
 
 extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
-                                 int n_prefix, int prefix_classes, int n_class, float* out_emb,
+                                 int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
                                  void* workspace, size_t workspace_bytes, int train, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 1, "text_forward: not a text tower");
         GRIP_REQUIRE(token_ids && eot_index && out_emb && (n_prefix == 0 || prefix), "text_forward: null pointer");
         GRIP_REQUIRE(n_prefix == 0 || prefix_classes == 1 || prefix_classes == n_class, "text_forward: prefix_classes must be 1 or n_class");
         Workspace w;
-        RUN(check_ws(t, n_class, n_prefix, train, workspace, workspace_bytes, w));
+        RUN(check_ws(t, n_class, n_prefix, train, workspace, workspace_bytes, w, seq_len));
         hipStream_t s = (hipStream_t)stream;
         const grip_dims& D = t->D;
         const int d = D.width;
         const half_t* W = t->w16;
         const float* F = t->w32;
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_text_embed(token_ids, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, n_class, D.seq0, d, D.vocab, s));
+        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, n_class, w.S, d, D.vocab, s));
         resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/1, s, &xf));
-        RUN(launch_gather_ln_f16(xf, eot_index, D.seq0, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, n_class, d, s));
+        RUN(launch_gather_ln_f16(xf, eot_index, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, n_class, d, s));
         GemmArgs a{};
         a.A = w.cls16; a.W = W + t->L.projT; a.M = n_class; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
         RUN(launch_gemm(EPI_F32, a, s));
@@ -473,7 +474,7 @@ extern "C" int grip_text_backward_prefix(grip_tower* t, const float* grad_emb, f
         hipStream_t s = (hipStream_t)stream;
         RUN(backward_head_of_tower(t, w, grad_emb, t->last_eot, s));
         RUN(run_blocks_backward(t, w, 1, s));
-        RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, w.batch, t->D.seq0, w.P, t->last_prefix_classes, t->D.width, s));
+        RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, w.batch, w.S, w.P, t->last_prefix_classes, t->D.width, s));
         return GRIP_OK;
     } catch (...) { grip_set_error("text_backward_prefix: exception"); return GRIP_ERR_ARG; }
 }

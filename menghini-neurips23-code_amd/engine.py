@@ -80,12 +80,12 @@ class Tower:
         self._finalized = True
 
     # ---- workspaces
-    def workspace(self, batch, n_prefix, train):
-        key = (batch, n_prefix, bool(train))
+    def workspace(self, batch, n_prefix, train, seq_len=0):
+        key = (batch, n_prefix, bool(train), seq_len)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = c_size_t()
-            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, int(train), byref(nbytes)))
+            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, seq_len, int(train), byref(nbytes)))
             if not train:   # inference workspaces are interchangeable: keep only the largest
                 for k in [k for k in self._ws if not k[2]]:
                     if self._ws[k].numel() >= nbytes.value:
@@ -135,7 +135,7 @@ class Tower:
             self._enc_streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
             self._enc_ws = {}
         nbytes = c_size_t()
-        native.check(self.lib.grip_workspace_bytes(self.handle, min(chunk, max(hi - lo, 1)), P, 0, byref(nbytes)))
+        native.check(self.lib.grip_workspace_bytes(self.handle, min(chunk, max(hi - lo, 1)), P, 0, 0, byref(nbytes)))
         for k in (0, 1):
             if k not in self._enc_ws or self._enc_ws[k].numel() < nbytes.value + 256:
                 self._enc_ws[k] = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
@@ -169,23 +169,29 @@ class Tower:
         native.check(self.lib.grip_vit_backward_prefix(self.handle, _ptr(grad_emb), _ptr(prefix), _ptr(g), p, n, _stream()))
         return g
 
-    def text_forward(self, token_ids, prefix=None, train=False):
+    # Encode only the positions up to the longest prompt's EOT: the text transformer is causal and only the EOT row is
+    # read, so later positions cannot influence any output (exact; the reference encodes all 77).
+    truncate_text_at_eot = True
+
+    def text_forward(self, token_ids, prefix=None, train=False, seq_len=None):
         if not self._finalized:
             self.finalize()
         assert self.kind == 1
         ids = token_ids.to(device=self.device, dtype=torch.int32).contiguous()
         eot = ids.argmax(dim=-1).to(torch.int32).contiguous()
         C = ids.shape[0]
+        if seq_len is None:
+            seq_len = min(int(eot.max().item()) + 1, self.seq0) if self.truncate_text_at_eot else 0
         P, pc = 0, 1
         if prefix is not None:
             pc, P = prefix.shape[0], prefix.shape[1]
             prefix = prefix.contiguous().float()
         out = torch.empty(C, self.embed_dim, dtype=torch.float32, device=self.device)
-        ws = self.workspace(C, P, train)
+        ws = self.workspace(C, P, train, seq_len)
         p, n = self._aligned(ws)
-        native.check(self.lib.grip_text_forward(self.handle, _ptr(ids), _ptr(eot), _ptr(prefix), P, pc, C, _ptr(out), p, n,
+        native.check(self.lib.grip_text_forward(self.handle, _ptr(ids), _ptr(eot), _ptr(prefix), P, pc, C, seq_len, _ptr(out), p, n,
                                                 int(train), _stream()))
-        return out, ws, (ids, eot)
+        return out, ws, (ids, eot, seq_len)
 
     def text_backward(self, grad_emb, prefix_shape, ws):
         grad_emb = grad_emb.contiguous().float()
@@ -231,7 +237,9 @@ class TextPrefixFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tower, token_ids, prefix):
         need = ctx.needs_input_grad[2]
-        out, ws, keep = tower.text_forward(token_ids, prefix.detach(), train=need)
+        cached = getattr(token_ids, "_grip_seq_len", None)
+        out, ws, keep = tower.text_forward(token_ids, prefix.detach(), train=need, seq_len=cached)
+        token_ids._grip_seq_len = keep[2]
         ctx.tower, ctx.ws = tower, ws
         ctx.keep = keep   # the native handle remembers the EOT-index pointer until backward
         ctx.pshape, ctx.pdtype = prefix.shape, prefix.dtype

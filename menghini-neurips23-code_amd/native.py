@@ -10,7 +10,7 @@ from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrip_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GripError(RuntimeError):
@@ -35,10 +35,10 @@ _SIGS = {
     "grip_tower_create": (c_int, [POINTER(Dims), c_void_p, c_void_p, POINTER(c_void_p)]),
     "grip_tower_finalize": (c_int, [c_void_p, c_void_p]),
     "grip_tower_destroy": (c_int, [c_void_p]),
-    "grip_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "grip_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
     "grip_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "grip_vit_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "grip_text_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "grip_text_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "grip_text_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "grip_cosine_head": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_cosine_head_backward": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -53,7 +53,7 @@ def test_bad_arguments_are_rejected(model):
         t.vit_forward(x, torch.zeros(100, 128, device="cuda"))            # more prompt tokens than the tower was built for
     tt = model.text_tower
     ids = torch.zeros(3, 77, dtype=torch.int32)
-    ids[:, 0], ids[:, 1] = 49406, 49407
+    ids[:, 0], ids[:, 1:7], ids[:, 7] = 49406, 343, 49407
     with pytest.raises(native.GripError, match="prefix_classes"):
         tt.text_forward(ids.cuda(), torch.zeros(2, 4, 128, device="cuda"))  # prefix for 2 classes, 3 prompts
     with pytest.raises(native.GripError, match="not a vision tower"):

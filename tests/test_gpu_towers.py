@@ -127,3 +127,31 @@ def test_text_vs_oracle_fresh_inputs(models, name, C, P, per_class):
     want = W.text_forward(om, ids, prefix)
     got, _, _ = m.text_tower.text_forward(ids.cuda(), prefix.cuda() if P else None)
     assert_embeddings_close(got, want.detach(), f"text {name} C={C} P={P}")
+
+
+def test_text_truncation_at_the_longest_eot_is_exact(models):
+    """Causal text tower, only the EOT row is read: encoding positions 0..max(EOT) gives the result of all 77."""
+    m = models("small")
+    g = torch.Generator().manual_seed(3)
+    ids = torch.zeros(9, 77, dtype=torch.int32)
+    for c in range(9):
+        n = 3 + c % 5
+        ids[c, 0] = 49406
+        ids[c, 1:1 + n] = torch.randint(1000, 40000, (n,), generator=g, dtype=torch.int32)
+        ids[c, 1 + n] = 49407
+    prefix = torch.randn(1, 2, 256, generator=g).cuda() * 0.05
+    tt = m.text_tower
+    full, _, _ = tt.text_forward(ids.cuda(), prefix, seq_len=0)
+    auto, _, keep = tt.text_forward(ids.cuda(), prefix)
+    assert keep[2] == 9                                   # longest prompt: SOT + 7 tokens + EOT
+    torch.testing.assert_close(auto, full, rtol=1e-5, atol=1e-5)
+    # gradients as well
+    from grip_amd.engine import TextPrefixFn
+    grads = []
+    for trunc in (True, False):
+        tt.truncate_text_at_eot = trunc
+        p = prefix.clone().requires_grad_(True)
+        (TextPrefixFn.apply(tt, ids.clone().cuda(), p) ** 2).sum().backward()
+        grads.append(p.grad.clone())
+    tt.truncate_text_at_eot = True
+    torch.testing.assert_close(grads[0], grads[1], rtol=1e-4, atol=1e-6)
