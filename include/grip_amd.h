@@ -149,6 +149,21 @@ int grip_weighted_ce(const float* logits, const int32_t* labels, const float* ro
                      float* loss, float* grad_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CLIP preprocessing of one decoded image: the `_transform` the reference applies per item on the host
+ * (data/dataset.py:64-79 via clip.load's preprocess): Resize(n_px, BICUBIC) -> CenterCrop(n_px) -> ToTensor -> Normalize.
+ * Bit-exact with Pillow's 8-bit bicubic resample; only the cropped rows / columns are produced.
+ *   img [H, W, 3] u8 device; out [3, n_px, n_px] f32 device; tmp [H * n_px * 3] u8 device scratch
+ *   hcoef [W_out, hksize] / hbounds [W_out, 2] and vcoef [H_out, vksize] / vbounds [H_out, 2]: int32 device tables of
+ *   Pillow's precompute_coeffs + normalize_coeffs_8bpc (22-bit fixed point; bounds = first input index, count);
+ *   hksize = vksize = 0 (tables NULL): the image already has the resized size, crop + normalise only.
+ *   mean3 / std3: HOST pointers to 3 floats. */
+int grip_preprocess_image(const uint8_t* img, int H, int W,
+                          const int32_t* hcoef, const int32_t* hbounds, int hksize, int W_out,
+                          const int32_t* vcoef, const int32_t* vbounds, int vksize, int H_out,
+                          int crop_left, int crop_top, int n_px, const float* mean3, const float* std3,
+                          uint8_t* tmp, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Sequential per-class leaderboard: utils/clip_pseudolabels.py:49-112 and the nine
  * assign_pseudo_labels (e.g. methods/transductive_zsl/multimodal_fpl.py:194-285).  Host function,
  * exact: order-dependent, one pass in dataset order.

@@ -61,14 +61,9 @@ def available_models():
     return [k for k in _cfg.CLIP_CONFIGS]
 
 
-def _preprocess(n_px):
-    def transform(img):
-        """CLIP preprocessing is a NEXT row; tensors pass through unchanged."""
-        if torch.is_tensor(img):
-            return img
-        raise NotImplementedError("PIL preprocessing is not part of the round-1 hot path; pass [3,R,R] tensors")
-    transform.n_px = n_px
-    return transform
+def _preprocess(n_px, device):
+    from ..preprocess import ClipPreprocess
+    return ClipPreprocess(n_px, device)
 
 
 def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0):
@@ -83,7 +78,7 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
     else:
         sd = {k: torch.from_numpy(v) for k, v in _weights.init_state_dict(d, seed).items()}
     load_openai_state_dict(m, sd)
-    return m, _preprocess(d.image_resolution)
+    return m, _preprocess(d.image_resolution, device)
 
 
 def load_openai_state_dict(m: CLIP, sd):

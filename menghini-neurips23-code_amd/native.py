@@ -43,6 +43,8 @@ _SIGS = {
     "grip_cosine_head": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_cosine_head_backward": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_weighted_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "grip_preprocess_image": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_leaderboard_scan": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
 }
 EXPORTS = tuple(_SIGS)   # the drop-in ABI (include/grip_amd.h)

@@ -1,0 +1,85 @@
+"""CLIP preprocessing: (CPU) the host-side coefficient tables drive a numpy emulation of the two-pass fixed-point resample
+that equals PIL.Image.resize(BICUBIC) bit for bit; (GPU) the HIP kernels give exactly what PIL + the reference's transform
+chain gives (Resize -> CenterCrop -> ToTensor -> Normalize), for down-, up- and no-scaling and odd sizes."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+SIZES = [(37, 53), (300, 500), (224, 224), (500, 375), (64, 64), (100, 31), (225, 224), (1, 900)]
+
+
+def _img(h, w, seed):
+    g = np.random.RandomState(seed)
+    base = g.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    base[::2, ::3] = 255
+    base[1::4] = 0
+    return base
+
+
+def _reference_transform(arr, n_px):
+    """openai-CLIP `_transform` with PIL + numpy (torchvision is not installed; it calls exactly these PIL ops)."""
+    from grip_amd.preprocess import MEAN, STD, resized_size
+    im = Image.fromarray(arr)
+    h, w = arr.shape[:2]
+    oh, ow = resized_size(h, w, n_px)
+    im = im.resize((ow, oh), Image.BICUBIC)
+    top, left = int(round((oh - n_px) / 2.0)), int(round((ow - n_px) / 2.0))
+    im = im.crop((left, top, left + n_px, top + n_px)).convert("RGB")
+    x = np.asarray(im, dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
+    return (x - np.array(MEAN, np.float32)[:, None, None]) / np.array(STD, np.float32)[:, None, None]
+
+
+def _emulate(arr, oh, ow):
+    import grip_amd  # noqa: F401
+    from grip_amd.preprocess import resample_coeffs
+    h, w = arr.shape[:2]
+    def one_pass(a, in_size, out_size):          # a: [in_size, other, 3] -> [out_size, other, 3]
+        coef, bounds, _ = resample_coeffs(in_size, out_size)
+        out = np.zeros((out_size,) + a.shape[1:], dtype=np.uint8)
+        for xx in range(out_size):
+            lo, cnt = bounds[xx]
+            acc = (a[lo:lo + cnt].astype(np.int64) * coef[xx, :cnt].astype(np.int64)[:, None, None]).sum(0) + (1 << 21)
+            out[xx] = np.clip(acc >> 22, 0, 255)
+        return out
+    t = one_pass(arr.transpose(1, 0, 2), w, ow).transpose(1, 0, 2)       # horizontal first, 8-bit intermediate
+    return one_pass(t, h, oh)
+
+
+@pytest.mark.parametrize("h,w", SIZES[:6])
+def test_coefficient_tables_reproduce_pillow_bicubic(h, w):
+    import grip_amd  # noqa: F401
+    from grip_amd.preprocess import resized_size
+    arr = _img(h, w, h * 31 + w)
+    oh, ow = resized_size(h, w, 32)
+    want = np.asarray(Image.fromarray(arr).resize((ow, oh), Image.BICUBIC))
+    assert np.array_equal(_emulate(arr, oh, ow), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", SIZES)
+@pytest.mark.parametrize("n_px", [224, 32])
+def test_gpu_preprocess_matches_pil_transform(h, w, n_px):
+    import grip_amd  # noqa: F401
+    from grip_amd.preprocess import ClipPreprocess
+    arr = _img(h, w, h + 7 * w)
+    pre = ClipPreprocess(n_px, "cuda")
+    got = pre(Image.fromarray(arr)).cpu().numpy()
+    want = _reference_transform(arr, n_px)
+    assert got.shape == (3, n_px, n_px)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)      # identical u8 pixels; float normalisation order only
+    got2 = pre(torch.from_numpy(arr)).cpu().numpy()                # uint8 tensor input path
+    assert np.array_equal(got, got2)
+
+
+@pytest.mark.gpu
+def test_clip_load_returns_the_gpu_preprocess_and_it_feeds_the_encoder():
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    m, preprocess = clip.load("small", device="cuda")
+    ims = [Image.fromarray(_img(80 + 5 * i, 120 - 7 * i, i)) for i in range(3)]
+    x = torch.stack([preprocess(im) for im in ims])
+    assert x.shape == (3, 3, 64, 64) and x.is_cuda
+    assert torch.isfinite(m.encode_image(x)).all()
+    t = torch.randn(3, 64, 64)
+    assert preprocess(t) is t                                      # already-preprocessed tensors pass through
