@@ -136,3 +136,40 @@ def test_assign_pseudo_labels_style_scan_uses_logit_argmax():
     probs = logits.softmax(-1).numpy()
     want = LB.leaderboard_scan(probs, logits.argmax(1).numpy(), paths, [5, 6, 7], 2)
     assert got == want
+
+
+def test_pseudolabel_top_k_from_image_files(tmp_path, monkeypatch):
+    """The reference's real input path: a dataset of FILE paths opened with PIL and pushed through the transform that
+    clip.load returned (here the GPU preprocess), against the oracle fed by the PIL/numpy transform chain."""
+    from PIL import Image
+
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    from grip_amd.utils import pseudolabel_top_k
+    from test_preprocess import _reference_transform
+    monkeypatch.chdir(tmp_path)
+    m, preprocess = clip.load("small", device="cuda")
+    g = np.random.RandomState(4)
+    paths, arrays = [], []
+    (tmp_path / "imgs").mkdir()
+    for i in range(40):
+        h, w = 70 + g.randint(0, 60), 70 + g.randint(0, 90)
+        base = g.randint(0, 256, size=(1, 1, 3)) * np.ones((h, w, 1)) * 0.7 + g.randint(0, 80, size=(h, w, 3))
+        arr = np.clip(base, 0, 255).astype(np.uint8)
+        p = str(tmp_path / "imgs" / f"{i:03d}.png")
+        Image.fromarray(arr).save(p)
+        paths.append(p)
+        arrays.append(arr)
+    classnames = ["forest", "river", "highway", "pasture"]
+    label_to_idx = {c: i for i, c in enumerate(classnames)}
+
+    class FileDataset:
+        def __init__(self, fp):
+            self.filepaths, self.labels = list(fp), None
+    ds = FileDataset(paths)
+    cfg = types.SimpleNamespace(LEARNING_PARADIGM="ul", MODEL="textual_fpl")
+    pseudolabel_top_k(cfg, "Files", 10000000, "a photo of a {}", ds, classnames, preprocess, m, label_to_idx, "cuda", "small", 1)
+    x = torch.from_numpy(np.stack([_reference_transform(a, 64) for a in arrays]))
+    (want_fp, want_lab), _ = _oracle_lists("small", x, paths, classnames, label_to_idx, 10000000, "a photo of a {}")
+    assert ds.filepaths == want_fp
+    assert np.mean(np.array(ds.labels) == np.array(want_lab)) >= 0.95
