@@ -106,9 +106,10 @@ class Loop:
             if len(my_img):
                 idx = (torch.arange(a.batch, device=self.device) + t * a.batch) % len(my_img)
                 x, y = self.pool[my_img[idx]], my_lab[idx]
-            else:
+                w = torch.full((a.batch,), 1.0 / a.batch, device=self.device)
+            else:   # no selected image lives in this rank's shard: same work, zero weight (it still joins the all-reduce)
                 x, y = self.pool[: a.batch], torch.zeros(a.batch, dtype=torch.int32, device=self.device)
-            w = torch.full((a.batch,), 1.0 / a.batch, device=self.device)
+                w = torch.zeros(a.batch, device=self.device)
             steps.coop_step(self.model, self.m, x, y, w, self.opt)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
