@@ -18,16 +18,9 @@ def _img(h, w, seed):
 
 
 def _reference_transform(arr, n_px):
-    """openai-CLIP `_transform` with PIL + numpy (torchvision is not installed; it calls exactly these PIL ops)."""
-    from grip_amd.preprocess import MEAN, STD, resized_size
-    im = Image.fromarray(arr)
-    h, w = arr.shape[:2]
-    oh, ow = resized_size(h, w, n_px)
-    im = im.resize((ow, oh), Image.BICUBIC)
-    top, left = int(round((oh - n_px) / 2.0)), int(round((ow - n_px) / 2.0))
-    im = im.crop((left, top, left + n_px, top + n_px)).convert("RGB")
-    x = np.asarray(im, dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
-    return (x - np.array(MEAN, np.float32)[:, None, None]) / np.array(STD, np.float32)[:, None, None]
+    """openai-CLIP `_transform` restated with PIL + numpy (oracle/preprocess.py)."""
+    from oracle.preprocess import clip_transform
+    return clip_transform(arr, n_px)
 
 
 def _emulate(arr, oh, ow):
