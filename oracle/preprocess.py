@@ -19,7 +19,7 @@ def resized_size(h, w, n_px):
 
 def clip_transform(img, n_px):
     """PIL image or uint8 [H,W,3] array -> float32 [3, n_px, n_px]."""
-    im = img if hasattr(img, "resize") else Image.fromarray(np.asarray(img, dtype=np.uint8))
+    im = img if isinstance(img, Image.Image) else Image.fromarray(np.asarray(img, dtype=np.uint8))
     w, h = im.size
     oh, ow = resized_size(h, w, n_px)
     im = im.resize((ow, oh), Image.BICUBIC)

@@ -49,6 +49,22 @@ def test_coefficient_tables_reproduce_pillow_bicubic(h, w):
     assert np.array_equal(_emulate(arr, oh, ow), want)
 
 
+@pytest.mark.parametrize("h,w", SIZES[:4])
+def test_oracle_transform_accepts_arrays_and_pil_and_matches_the_emulation(h, w):
+    import grip_amd  # noqa: F401
+    from grip_amd.preprocess import MEAN, STD, resized_size
+    arr = _img(h, w, h + 5 * w)
+    a = _reference_transform(arr, 32)
+    b = _reference_transform(Image.fromarray(arr), 32)
+    assert a.shape == (3, 32, 32) and np.array_equal(a, b)
+    oh, ow = resized_size(h, w, 32)
+    px = _emulate(arr, oh, ow)
+    top, left = int(round((oh - 32) / 2.0)), int(round((ow - 32) / 2.0))
+    px = px[top:top + 32, left:left + 32].astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
+    want = (px - np.array(MEAN, np.float32)[:, None, None]) / np.array(STD, np.float32)[:, None, None]
+    np.testing.assert_allclose(a, want, rtol=0, atol=1e-6)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("h,w", SIZES)
 @pytest.mark.parametrize("n_px", [224, 32])
