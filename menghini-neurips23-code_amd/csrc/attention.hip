@@ -1,5 +1,6 @@
 // Fused multi-head self-attention for the CLIP towers (head dim 64, S <= 640): the whole K and V of
-// one (image, head) live in LDS, a workgroup of 4 waves walks the 16-row query tiles.
+// one (image, head) live in LDS, a workgroup of 8 waves (4 for S <= 96) walks the 16-row query tiles: two workgroups
+// fit a CU's LDS at S = 197, so 8 waves each puts 4 waves on every SIMD to cover the staging and softmax latency.
 //
 //   scores^T = K (Q/8)^T   per 16x16 tile with v_mfma_f32_16x16x32_f16 (A = K rows from LDS,
 //                          B = Q rows straight from HBM); the transposed product leaves every lane
@@ -17,8 +18,8 @@
 
 #include "common.h"
 
-template <int KVC, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H) {
+template <int KVC, bool CAUSAL, int ATT_NW>
+__global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H) {
     constexpr int SP = KVC * 32;
     constexpr int VST = SP + 8;
     constexpr float LOG2E = 1.4426950408889634f;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const half_t* __restrict_
     load_q(wave < n_qt ? wave : 0, q_next);
 
     // K: [kv][64] rows, 16-byte chunk index XOR (kv & 7).
-    for (int idx = tid; idx < SP * 8; idx += 256) {
+    for (int idx = tid; idx < SP * 8; idx += ATT_NW * 64) {
         const int row = idx >> 3, chunk = idx & 7;
         half8 kv = {0, 0, 0, 0, 0, 0, 0, 0};
         if (row < S) kv = *(const half8*)(base + row * ld + D + chunk * 8);
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const half_t* __restrict_
     // V^T: [64][VST].  A lane takes a PAIR of keys (2r, 2r+1) and one 8-wide slice of the head dim and writes
     // eight 32-bit words {V[2r][d], V[2r+1][d]}: lanes 0-31 cover 32 consecutive words of one d row (no bank
     // conflict), lanes 32-63 the neighbouring slice (other half-wave group of ds_write_b32).
-    for (int idx = tid; idx < ((SP / 2 + 31) / 32) * 256; idx += 256) {
+    for (int idx = tid; idx < ((SP / 2 + 31) / 32) * 256; idx += ATT_NW * 64) {
         const int lane_rp = idx & 31, chunk = ((idx >> 5) & 1) + 2 * ((idx >> 6) & 3), rblk = idx >> 8;
         const int rp = rblk * 32 + lane_rp;          // key pair index
         const int r0 = 2 * rp;
@@ -68,11 +69,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const half_t* __restrict_
     }
     __syncthreads();
 
-    for (int qt = wave; qt < n_qt; qt += 4) {
+    for (int qt = wave; qt < n_qt; qt += ATT_NW) {
         asm volatile("" ::: "memory");  // keep the K/V fragment reads inside the tile loop (hoisting them costs >100 VGPRs)
         const int qrow = qt * 16 + li;
         half8 qf[2] = {q_next[0], q_next[1]};
-        if (qt + 4 < n_qt) load_q(qt + 4, q_next);
+        if (qt + ATT_NW < n_qt) load_q(qt + ATT_NW, q_next);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) qf[kk] *= (half_t)0.125f;  // 1/sqrt(64), exact in f16
         f32x4 sc[2 * KVC];
@@ -140,16 +141,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const half_t* __restrict_
     }
 }
 
-template <int KVC, bool CAUSAL>
+template <int KVC, bool CAUSAL, int ATT_NW>
 static int launch_one(const half_t* qkv, half_t* out, int B, int S, int H, hipStream_t s) {
     constexpr int SP = KVC * 32;
     constexpr size_t lds = (size_t)SP * 64 * 2 + (size_t)64 * (SP + 8) * 2;
     static bool configured = false;
     if (!configured) {
-        GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<KVC, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<KVC, CAUSAL, ATT_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<KVC, CAUSAL>), dim3(B * H), dim3(256), lds, s, qkv, out, S, H);
+    hipLaunchKernelGGL((attn_fwd_kernel<KVC, CAUSAL, ATT_NW>), dim3(B * H), dim3(ATT_NW * 64), lds, s, qkv, out, S, H);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
@@ -159,8 +160,8 @@ int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, in
     GRIP_REQUIRE(S >= 1 && kvc <= 19, "attention: sequence length %d unsupported (max 608)", S);
     // exact chunk count (the kernel relies on (KVC-1)*32 < S); 11..18 share the 19-chunk build via the slow mask path
 #define GRIP_ATTN(N)                                                        \
-    if (kvc == N) return causal ? launch_one<N, true>(qkv, out, B, S, H, s) \
-                                : launch_one<N, false>(qkv, out, B, S, H, s);
+    if (kvc == N) return causal ? launch_one<N, true, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s) \
+                                : launch_one<N, false, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s);
     GRIP_ATTN(1) GRIP_ATTN(2) GRIP_ATTN(3) GRIP_ATTN(4) GRIP_ATTN(5) GRIP_ATTN(6) GRIP_ATTN(7) GRIP_ATTN(8) GRIP_ATTN(9) GRIP_ATTN(10)
     GRIP_ATTN(11) GRIP_ATTN(12) GRIP_ATTN(13) GRIP_ATTN(14) GRIP_ATTN(15) GRIP_ATTN(16) GRIP_ATTN(17) GRIP_ATTN(18) GRIP_ATTN(19)
 #undef GRIP_ATTN

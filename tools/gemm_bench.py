@@ -38,6 +38,22 @@ def run(M, N, K, epi, variant, reps=20):
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
+def run_lib(M, N, K, reps=20):
+    """Yardstick only (never on the product path): the vendor library GEMM torch dispatches to, same shape, no epilogue."""
+    A = torch.randn(M, K, device="cuda").half()
+    W = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+    for _ in range(3):
+        torch.nn.functional.linear(A, W)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        torch.nn.functional.linear(A, W)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+
 imgs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 M = imgs * 197
 shapes = [("qkv", 2304, 768, 1), ("out", 768, 768, 3), ("fc", 3072, 768, 2), ("proj", 768, 3072, 3), ("f32", 768, 768, 0)]
@@ -46,4 +62,5 @@ if len(sys.argv) > 2 and sys.argv[2] == "text":
     shapes = [("qkv", 1536, 512, 1), ("out", 512, 512, 3), ("fc", 2048, 512, 2), ("proj", 512, 2048, 3), ("dln", 512, 1536, 0)]
 for name, N, K, epi in shapes:
     r = [run(M, N, K, epi, v) for v in (1, 2, 3, 4, 0)]
-    print(f"{name:5s} M={M} N={N} K={K}: " + " | ".join(f"{nm} {m:.3f} ms {t:.0f} TF/s" for nm, (m, t) in zip(("128x128", "256x256", "256x128", "64x128", "auto"), r)), flush=True)
+    print(f"{name:5s} M={M} N={N} K={K}: " + " | ".join(f"{nm} {m:.3f} ms {t:.0f} TF/s" for nm, (m, t) in zip(("128x128", "256x256", "256x128", "64x128", "auto"), r))
+          + (" | lib(no epilogue) %.3f ms %.0f TF/s" % run_lib(M, N, K) if __import__("os").environ.get("LIB") else ""), flush=True)
