@@ -8,21 +8,105 @@
 //                          reductions are in-register + two xor-shuffles (lanes 16/32 apart).
 //   P = exp(s - max)       f32, packed to f16 in place: two score tiles form one 32-wide K chunk of
 //                          the second MFMA without any cross-lane movement.
-//   O^T = V^T P^T          A = V^T fragments read as 2 x ds_read_b64 from a transposed LDS copy
-//                          (row stride SP+8 halfs => conflict-free), B = the packed P registers.
+//   O^T = V^T P^T          A = V^T fragments, one ds_read_b128 each from a blocked LDS image of V (vt_index below),
+//                          B = the packed P registers.
 //                          Each lane ends with 4 consecutive head-dim values of its own query row,
 //                          divides by its own row sum and stores 8 bytes.
 // K is stored [kv][64] with the 16-byte chunk index XOR (kv & 7): conflict-free ds_read_b128.
 // Padding keys (kv >= S) are zero-filled and masked to -inf; causal masking for the text tower.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
+
+// LDS image of V for the P.V MFMA (A operand = V^T fragment, 16 head dims x 32 keys).  Per (32-key chunk c, 16-dim block
+// nf) one 1 KiB block in which lane (li, lg) of the consuming wave finds its 8 halfs -- keys c*32 + lg*4 + {0..3} and
+// c*32 + 16 + lg*4 + {0..3} of head dim nf*16 + li -- at 16-byte unit lg*16 + (li ^ lg): one ds_read_b128 per MFMA,
+// conflict-free in the instruction's four 16-lane groups, and the staging writes (32 lanes = 32 key pairs of one dim)
+// spread over 16 banks.  (The earlier [dim][key] image needed two ds_read_b64, which the compiler fuses into a
+// ds_read2_b64: 8 LDS cycles + 2-way conflicts instead of 4.)
+__device__ __forceinline__ int vt_index(int key, int d) {
+    const int c = key >> 5, kk = key & 31, lg = (kk >> 2) & 3, e = (kk >> 4) * 4 + (kk & 3);
+    return (((c * 4 + (d >> 4)) * 64 + lg * 16 + ((d & 15) ^ lg)) * 8) + e;
+}
+
+// IEEE-754-2019 maximum: compiles to v_maximum3_f32 (two ops per four scores); fmaxf chains cost a v_max per pair plus a
+// canonicalising v_max per MFMA result.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
+
+// One 16-row query tile against the K / V^T of one (image, head) held in LDS: scores, softmax, P.V, store.
+// qf = the tile's two Q fragments (unscaled); orow = the output row pointer of this lane's query (+ head offset).
+template <int KVC, bool CAUSAL>
+__device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, half8 (&qf)[2], int qrow, int S, half_t* orow, int lane) {
+    constexpr int SP = KVC * 32;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] *= (half_t)0.125f;  // 1/sqrt(64), exact in f16
+    f32x4 sc[2 * KVC];
+    float m = -INFINITY;
+    // The launcher guarantees (KVC-1)*32 < S <= KVC*32: every tile before the last 32-key chunk is full, so
+    // only the last two tiles (and causal rows) pay for the mask; the code stays one straight-line block.
+#pragma unroll
+    for (int t = 0; t < 2 * KVC; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half8 kf = *(const half8*)(Ks + (t * 16 + li) * 64 + (((kk * 4 + lg) ^ (lane & 7)) * 8));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], acc, 0, 0, 0);
+        }
+        if (CAUSAL || t >= 2 * (KVC - 1)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kv = t * 16 + lg * 4 + r;
+                if (kv >= S || (CAUSAL && kv > qrow)) acc[r] = -INFINITY;
+            }
+        }
+        m = max3(max3(m, acc[0], acc[1]), acc[2], acc[3]);
+        sc[t] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float m2 = m * LOG2E;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2 * KVC; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -m2));   // exp(s - m)
+            sc[t][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) o[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KVC; ++c) {
+        const half8 pf = {(half_t)sc[2 * c][0], (half_t)sc[2 * c][1], (half_t)sc[2 * c][2], (half_t)sc[2 * c][3],
+                          (half_t)sc[2 * c + 1][0], (half_t)sc[2 * c + 1][1], (half_t)sc[2 * c + 1][2], (half_t)sc[2 * c + 1][3]};
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const half8 vf = *(const half8*)(Vt + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
+            o[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[nf], 0, 0, 0);
+        }
+    }
+    if (qrow < S) {
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        half_t* op = orow + lg * 4;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const f32x4 v = o[nf] * inv;
+            *(half4*)(op + nf * 16) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+    }
+}
 
 template <int KVC, bool CAUSAL, int ATT_NW>
 __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H) {
     constexpr int SP = KVC * 32;
-    constexpr int VST = SP + 8;
-    constexpr float LOG2E = 1.4426950408889634f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Ks = (half_t*)smem;
     half_t* Vt = Ks + SP * 64;
@@ -53,9 +137,8 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __r
         if (row < S) kv = *(const half8*)(base + row * ld + D + chunk * 8);
         *(half8*)(Ks + row * 64 + ((chunk ^ (row & 7)) * 8)) = kv;
     }
-    // V^T: [64][VST].  A lane takes a PAIR of keys (2r, 2r+1) and one 8-wide slice of the head dim and writes
-    // eight 32-bit words {V[2r][d], V[2r+1][d]}: lanes 0-31 cover 32 consecutive words of one d row (no bank
-    // conflict), lanes 32-63 the neighbouring slice (other half-wave group of ds_write_b32).
+    // V image (vt_index).  A lane takes a PAIR of keys (2r, 2r+1) and one 8-wide slice of the head dim and writes
+    // eight 32-bit words {V[2r][d], V[2r+1][d]}; lanes 0-31 are 32 consecutive key pairs, lanes 32-63 the next slice.
     for (int idx = tid; idx < ((SP / 2 + 31) / 32) * 256; idx += ATT_NW * 64) {
         const int lane_rp = idx & 31, chunk = ((idx >> 5) & 1) + 2 * ((idx >> 6) & 3), rblk = idx >> 8;
         const int rp = rblk * 32 + lane_rp;          // key pair index
@@ -65,7 +148,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __r
         if (r0 < S) v0 = *(const half8*)(base + r0 * ld + 2 * D + chunk * 8);
         if (r0 + 1 < S) v1 = *(const half8*)(base + (r0 + 1) * ld + 2 * D + chunk * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *(half2v*)(Vt + (chunk * 8 + j) * VST + r0) = (half2v){v0[j], v1[j]};
+        for (int j = 0; j < 8; ++j) *(half2v*)(Vt + vt_index(r0, chunk * 8 + j)) = (half2v){v0[j], v1[j]};
     }
     __syncthreads();
 
@@ -74,77 +157,152 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __r
         const int qrow = qt * 16 + li;
         half8 qf[2] = {q_next[0], q_next[1]};
         if (qt + ATT_NW < n_qt) load_q(qt + ATT_NW, q_next);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] *= (half_t)0.125f;  // 1/sqrt(64), exact in f16
-        f32x4 sc[2 * KVC];
-        float m = -INFINITY;
-        // The launcher guarantees (KVC-1)*32 < S <= KVC*32: every tile before the last 32-key chunk is full, so
-        // only the last two tiles (and causal rows) pay for the mask; the code stays one straight-line block.
-#pragma unroll
-        for (int t = 0; t < 2 * KVC; ++t) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const half8 kf = *(const half8*)(Ks + (t * 16 + li) * 64 + (((kk * 4 + lg) ^ (lane & 7)) * 8));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], acc, 0, 0, 0);
-            }
-            if (CAUSAL || t >= 2 * (KVC - 1)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kv = t * 16 + lg * 4 + r;
-                    if (kv >= S || (CAUSAL && kv > qrow)) acc[r] = -INFINITY;
-                }
-            }
-            m = fmaxf(fmaxf(m, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
-            sc[t] = acc;
-        }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        const float m2 = m * LOG2E;
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2 * KVC; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -m2));   // exp(s - m)
-                sc[t][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-
-        f32x4 o[4];
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) o[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < KVC; ++c) {
-            const half8 pf = {(half_t)sc[2 * c][0], (half_t)sc[2 * c][1], (half_t)sc[2 * c][2], (half_t)sc[2 * c][3],
-                              (half_t)sc[2 * c + 1][0], (half_t)sc[2 * c + 1][1], (half_t)sc[2 * c + 1][2], (half_t)sc[2 * c + 1][3]};
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const half_t* vp = Vt + (nf * 16 + li) * VST + c * 32 + lg * 4;
-                const half4 v0 = *(const half4*)vp;
-                const half4 v1 = *(const half4*)(vp + 16);
-                const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[nf], 0, 0, 0);
-            }
-        }
-        if (qrow < S) {
-            const float inv = __builtin_amdgcn_rcpf(sum);
-            half_t* op = out + ((size_t)b * S + qrow) * D + h * 64 + lg * 4;
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const f32x4 v = o[nf] * inv;
-                *(half4*)(op + nf * 16) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            }
-        }
+        attn_tile<KVC, CAUSAL>(Ks, Vt, qf, qrow, S, out + ((size_t)b * S + qrow) * D + h * 64, lane);
     }
+}
+
+// ---- Pipelined variant for the pool encode (non-causal, S <= 288): persistent workgroups, one per CU, walk the
+// (image, head) items with TWO K / V^T buffers in LDS.  While the waves work on item i, item i+1 is already on its way:
+//   K    HBM -> LDS by global_load_lds (no registers, no waits; the XOR swizzle is applied to the SOURCE chunk index),
+//   V    HBM -> registers at the top of the item, transposed into the other buffer's V^T after the item's last tile,
+//   Q    the wave's query fragments for item i+1.
+// One barrier per item.  The plain kernel above runs staging and compute back to back (measured 96 us + 98 us of a
+// 176 us launch at 440 x 12 heads, S = 197: no overlap, the two co-resident workgroups move in lock step); this one
+// takes 169 us.  (An 8-wave variant with batched fragment reads, for more registers per wave, was slower: 191 us.)
+template <int KVC, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H, int n_items) {
+    constexpr int SP = KVC * 32;
+    constexpr int BUF = 2 * SP * 64;                            // halfs per buffer (K rows + V image)
+    constexpr int NQ = (2 * KVC + NW - 1) / NW;                 // query tiles per wave
+    constexpr int V_ITEMS = ((SP / 2 + 31) / 32) * 256;         // (key pair, 8-wide head-dim slice) units
+    constexpr int NV = (V_ITEMS + NW * 64 - 1) / (NW * 64);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* lds = (half_t*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = H * 64;
+    const size_t ld = (size_t)3 * D;
+    const int li = lane & 15, lg = lane >> 4;
+    const int n_qt = (S + 15) >> 4;
+
+    auto item_base = [&](int item) {
+        const int b = item / H, h = item - b * H;
+        return qkv + (size_t)b * S * ld + h * 64;
+    };
+    // K rows 8 at a time per wave instruction; LDS slot (row, c) receives source chunk c ^ (row & 7).  Rows >= S repeat
+    // row S-1 (their scores are masked to -inf whatever they hold).
+    auto issue_k = [&](const half_t* base, int buf) {
+        for (int g = wave; g < SP / 8; g += NW) {
+            int row = g * 8 + (lane >> 3);
+            row = row < S ? row : S - 1;
+            const half_t* src = base + (size_t)row * ld + D + (((lane & 7) ^ (lane >> 3)) * 8);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(lds + buf * BUF + g * 512), 16, 0, 0);
+        }
+    };
+    half8 v0[NV], v1[NV];
+    auto load_v = [&](const half_t* base) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int idx = tid + n * NW * 64;
+            const int lane_rp = idx & 31, chunk = ((idx >> 5) & 1) + 2 * ((idx >> 6) & 3), rblk = idx >> 8;
+            const int r0 = 2 * (rblk * 32 + lane_rp);
+            v0[n] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            v1[n] = (half8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (r0 < S) v0[n] = *(const half8*)(base + (size_t)r0 * ld + 2 * D + chunk * 8);
+            if (r0 + 1 < S) v1[n] = *(const half8*)(base + (size_t)(r0 + 1) * ld + 2 * D + chunk * 8);
+        }
+    };
+    auto store_v = [&](int buf) {
+        half_t* Vt = lds + buf * BUF + SP * 64;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int idx = tid + n * NW * 64;
+            const int lane_rp = idx & 31, chunk = ((idx >> 5) & 1) + 2 * ((idx >> 6) & 3), rblk = idx >> 8;
+            const int r0 = 2 * (rblk * 32 + lane_rp);
+            if (r0 < SP) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *(half2v*)(Vt + vt_index(r0, chunk * 8 + j)) = (half2v){v0[n][j], v1[n][j]};
+            }
+        }
+    };
+    half8 q[NQ][2];
+    auto load_q = [&](const half_t* base) {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            const int qrow = (wave + n * NW) * 16 + li;
+            const int qr = qrow < S ? qrow : S - 1;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) q[n][kk] = *(const half8*)(base + (size_t)qr * ld + (kk * 4 + lg) * 8);
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    {
+        const half_t* base = item_base(item);
+        issue_k(base, 0);
+        load_v(base);
+        load_q(base);
+        store_v(0);
+    }
+    for (int it = 0;; ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the item's K has landed
+        __syncthreads();                                    // ... everyone's has, V^T is written, and buffer buf^1 is free
+        const int next = item + gridDim.x;
+        const bool has_next = next < n_items;
+        half8 qf[NQ][2];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) { qf[n][0] = q[n][0]; qf[n][1] = q[n][1]; }
+        if (has_next) {
+            const half_t* nb = item_base(next);
+            issue_k(nb, buf ^ 1);
+            load_v(nb);
+            load_q(nb);
+        }
+        const int b = item / H, h = item - b * H;
+        const half_t* Ks = lds + buf * BUF;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            const int qt = wave + n * NW;
+            if (qt < n_qt) {
+                asm volatile("" ::: "memory");
+                const int qrow = qt * 16 + li;
+                attn_tile<KVC, false>(Ks, Ks + SP * 64, qf[n], qrow, S, out + ((size_t)b * S + qrow) * D + h * 64, lane);
+            }
+        }
+        if (!has_next) break;
+        store_v(buf ^ 1);
+        item = next;
+    }
+}
+
+template <int KVC, int NW>
+static int launch_pipe(const half_t* qkv, half_t* out, int B, int S, int H, hipStream_t s) {
+    constexpr int SP = KVC * 32;
+    constexpr size_t lds = 2 * ((size_t)2 * SP * 64 * 2);
+    static int resident = 0;     // workgroups the device holds at once (LDS- or register-limited), = the persistent grid
+    if (!resident) {
+        GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<KVC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0, n_cu = 0, per_cu = 0;
+        GRIP_CHECK_HIP(hipGetDevice(&dev));
+        GRIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        GRIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_fwd_pipe_kernel<KVC, NW>, NW * 64, lds));
+        GRIP_REQUIRE(per_cu >= 1, "attention: pipelined kernel does not fit a CU (KVC %d)", KVC);
+        resident = n_cu * per_cu;
+    }
+    const int n_items = B * H;
+    const int grid = n_items < resident ? n_items : resident;
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<KVC, NW>), dim3(grid), dim3(NW * 64), lds, s, qkv, out, S, H, n_items);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
 }
 
 template <int KVC, bool CAUSAL, int ATT_NW>
 static int launch_one(const half_t* qkv, half_t* out, int B, int S, int H, hipStream_t s) {
     constexpr int SP = KVC * 32;
-    constexpr size_t lds = (size_t)SP * 64 * 2 + (size_t)64 * (SP + 8) * 2;
+    constexpr size_t lds = (size_t)2 * SP * 64 * 2;
     static bool configured = false;
     if (!configured) {
         GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<KVC, CAUSAL, ATT_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -158,7 +316,15 @@ static int launch_one(const half_t* qkv, half_t* out, int B, int S, int H, hipSt
 int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s) {
     const int kvc = (S + 31) / 32;
     GRIP_REQUIRE(S >= 1 && kvc <= 19, "attention: sequence length %d unsupported (max 608)", S);
-    // exact chunk count (the kernel relies on (KVC-1)*32 < S); 11..18 share the 19-chunk build via the slow mask path
+    // exact chunk count (the kernel relies on (KVC-1)*32 < S)
+    // The persistent double-buffered kernel serves the pool encode of the 197..224-token towers (16 waves fit the
+    // 128-VGPR budget up to 7 chunks); GRIP_ATTN_PIPE=0 switches it off (developer A/B).
+    static const bool pipe = !(getenv("GRIP_ATTN_PIPE") && atoi(getenv("GRIP_ATTN_PIPE")) == 0);
+    if (!causal && pipe && B * H >= 1024) {      // enough items for every CU to pipeline over several
+        if (kvc == 5) return launch_pipe<5, 16>(qkv, out, B, S, H, s);
+        if (kvc == 6) return launch_pipe<6, 16>(qkv, out, B, S, H, s);
+        if (kvc == 7) return launch_pipe<7, 16>(qkv, out, B, S, H, s);
+    }
 #define GRIP_ATTN(N)                                                        \
     if (kvc == N) return causal ? launch_one<N, true, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s) \
                                 : launch_one<N, false, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s);

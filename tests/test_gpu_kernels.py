@@ -98,7 +98,10 @@ def test_gemm_is_not_transposed():
     torch.testing.assert_close(out, W.float().t())
 
 
-@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (3, 33, 2, 0), (2, 77, 8, 1), (2, 197, 12, 0), (2, 213, 12, 0), (1, 257, 4, 0), (1, 593, 2, 0)])
+@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (3, 33, 2, 0), (2, 77, 8, 1), (2, 197, 12, 0), (2, 213, 12, 0), (1, 257, 4, 0), (1, 593, 2, 0),
+                                          # >= 1024 (image, head) items: the persistent double-buffered encode kernel, every chunk count it serves
+                                          (100, 197, 12, 0), (300, 100, 4, 0), (90, 130, 12, 0), (70, 180, 16, 0), (70, 213, 16, 0), (70, 250, 16, 0),
+                                          (64, 273, 16, 0), (257, 288, 4, 0)])
 def test_attention(B, S, H, causal):
     native, lib = _lib()
     g = torch.Generator(device="cuda").manual_seed(S)
