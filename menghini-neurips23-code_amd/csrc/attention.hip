@@ -68,18 +68,16 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
     m = fmaxf(m, __shfl_xor(m, 16));
     m = fmaxf(m, __shfl_xor(m, 32));
     const float m2 = m * LOG2E;
-    float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2 * KVC; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -m2));   // exp(s - m)
-            sc[t][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+        for (int r = 0; r < 4; ++r) sc[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -m2));   // exp(s - m)
 
+    // The row sums come out of the matrix pipe: a fifth accumulator takes an all-ones A operand, so every row of it is
+    // sum_k P[q][k] for the lane's own query (56 v_add and two cross-lane steps per tile less on the VALU, which is the
+    // busier pipe here; the sum is over the f16-rounded numerators, i.e. exactly what the P.V product uses).
+    const half8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+    f32x4 osum = {0.f, 0.f, 0.f, 0.f};
     f32x4 o[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) o[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -92,9 +90,10 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
             const half8 vf = *(const half8*)(Vt + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
             o[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[nf], 0, 0, 0);
         }
+        osum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf, osum, 0, 0, 0);
     }
     if (qrow < S) {
-        const float inv = __builtin_amdgcn_rcpf(sum);
+        const float inv = __builtin_amdgcn_rcpf(osum[0]);
         half_t* op = orow + lg * 4;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
