@@ -54,11 +54,16 @@ def run_lib(M, N, K, reps=20):
     return ms, 2.0 * M * N * K / ms / 1e9
 
 
-imgs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+arg1 = sys.argv[1] if len(sys.argv) > 1 else "256"
+imgs = 0 if arg1.startswith("M=") else int(arg1)
 M = imgs * 197
 shapes = [("qkv", 2304, 768, 1), ("out", 768, 768, 3), ("fc", 3072, 768, 2), ("proj", 768, 3072, 3), ("f32", 768, 768, 0)]
+if arg1.startswith("M=") and not (len(sys.argv) > 2 and sys.argv[2] == "text"):
+    M = int(arg1[2:])
 if len(sys.argv) > 2 and sys.argv[2] == "text":
     M = imgs * 77
+    if arg1.startswith("M="):
+        M = int(arg1[2:])
     shapes = [("qkv", 1536, 512, 1), ("out", 512, 512, 3), ("fc", 2048, 512, 2), ("proj", 512, 2048, 3), ("dln", 512, 1536, 0)]
 for name, N, K, epi in shapes:
     r = [run(M, N, K, epi, v) for v in (1, 2, 3, 4, 0)]
