@@ -59,12 +59,23 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
     // the loads of pass p+1 go out before the stores of pass p, so no load ever queues behind a store.
     half4 res[2][8];
     half4 aux[2][8];
+    // Addresses: one 32-bit element offset per lane plus a wave-uniform step per row group, against the uniform base
+    // pointers (saddr + voffset addressing, one VGPR per access).  With 64-bit per-row pointers the compiler materialises
+    // all 64 of them at the top of the epilogue and spills them when the main loop leaves < 10 free registers.
+    const uint32_t lane_off = (uint32_t)(row0 + rr) * (uint32_t)ldc + (uint32_t)col;      // M * ldc < 2^31 elements (launcher)
+    auto elem_off = [&](int p, int it) -> uint32_t {
+        if constexpr (CHECK) {
+            int row = row0 + p * 32 + it * 4 + rr;
+            row = row < g.M ? row : g.M - 1;
+            return (uint32_t)row * (uint32_t)ldc + (uint32_t)col;
+        } else {
+            return lane_off + (uint32_t)((p * 32 + it * 4) * ldc);
+        }
+    };
     auto prefetch = [&](int p, int b) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            int row = row0 + p * 32 + it * 4 + rr;
-            row = row < g.M ? row : g.M - 1;
-            const size_t o = (size_t)row * ldc + col;
+            const uint32_t o = elem_off(p, it);
             if constexpr (EPI == EPI_BIAS_RESID) res[b][it] = *(const half4*)(g.resid + o);
             if constexpr (EPI == EPI_GELUGRAD_F16) aux[b][it] = *(const half4*)(g.aux + o);
         }
@@ -84,7 +95,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
             const int rl = it * 4 + rr;
             f32x4 v = *(const f32x4*)(slab + rl * EPI_LDW + cc);
             const int row = row0 + p * 32 + rl;
-            const size_t o = (size_t)row * ldc + col;
+            const uint32_t o = CHECK ? (uint32_t)row * (uint32_t)ldc + (uint32_t)col : elem_off(p, it);
             if constexpr (HAS_BIAS) v += bias4;
             if (!CHECK || row < g.M) {
                 if constexpr (EPI == EPI_F32) {
@@ -401,13 +412,129 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     epilogue_rows<EPI, 8>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
+// ---- 256x256 tile, K staged 64 wide: every DMA instruction moves 8 rows x 128 B, i.e. whole cache lines (the 32-wide
+// ring above asks the L2 for 64-byte half lines; tools/micro/dma_feed.hip: 14 TB/s vs 21 TB/s into LDS over 256 CUs).
+// Two 64 KiB stages; each stage is multiplied as two 32-wide sub-steps with register double-buffered fragments.  One
+// raw barrier per stage sits BETWEEN the sub-steps: at that point every wave has all fragments of stage t in registers
+// (so slot t&1 can be refilled with stage t+2) and stage t+1, issued one stage earlier, is certified, so its first
+// fragments are fetched under the second sub-step's MFMAs.  NW = 8: waves 128x64, two per SIMD.  (A four-wave build of this and of the ring -- 128x128 per wave, accumulators in
+// the 256 AGPRs, a third less LDS fragment traffic -- measured 5-25 % slower: one wave per SIMD leaves the barrier, DMA
+// issue and epilogue uncovered.)
+template <int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int BMT = 256, BNT = 256;
+    constexpr int WN = NW / 2;                    // waves along N
+    constexpr int WCOLS = BNT / WN;               // 64 or 128
+    constexpr int NJ = WCOLS / 16;
+    constexpr int STAGE = (BMT + BNT) * BK;       // halfs per stage (BK = 64)
+    constexpr int GI = (BMT + BNT) / 8 / NW;      // DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) half_t lds2[];
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BMT, n0 = tn * BNT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave - wr * WN;
+
+    // staging: wave w moves rows [w*GI*8, +GI*8) of the 512-row (A then W) stage, 8 rows per instruction;
+    // lane l -> row l>>3, LDS chunk l&7, source chunk (l&7)^(l>>3)
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const size_t K = (size_t)g.K;
+    const int r0 = wave * GI * 8;                 // uniform: this wave's rows are all A rows or all W rows (GI*8 divides 256)
+    const half_t* src = (r0 < BMT ? g.A + (size_t)(m0 + r0 + srow) * K : g.W + (size_t)(n0 + r0 - BMT + srow) * K) + schunk * 8;
+    auto stage = [&](int buf, int kt) {
+        half_t* dst = lds2 + buf * STAGE + r0 * BK;
+        const half_t* sp = src + (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < GI; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)i * 8 * K), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
+        a_off[kk] = (wr * 128 + frow) * BK + chunk * 8;
+        b_off[kk] = BMT * BK + (wc * WCOLS + frow) * BK + chunk * 8;
+    }
+
+    f32x4 acc[NJ / 4][8][4];
+#pragma unroll
+    for (int h = 0; h < NJ / 4; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    half8 fa[2][8], fb[2][NJ];
+    auto load_frags = [&](int set, int buf, int kk) {
+        const half_t* st = lds2 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[set][j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[set][i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+    };
+    auto mfma_set = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[j >> 2][i][j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[set][j], fa[set][i], acc[j >> 2][i][j & 3], 0, 0, 0);
+    };
+    auto spread = [&]() {     // interleave the (8 + NJ) fragment reads of the other set with this set's 8*NJ MFMAs
+#pragma unroll
+        for (int q = 0; q < 8 + NJ; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (8 * NJ) / (8 + NJ) > 3 ? 3 : 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+
+    const int nk = g.K / BK;    // >= 2 (checked by the launcher)
+    stage(0, 0);
+    stage(1, 1);
+    wait_vmcnt<GI>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        // sub-step 0
+        load_frags(1, buf, 1);
+        mfma_set(0);
+        spread();
+        // stage boundary
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) stage(buf, kt + 2);
+        // sub-step 1
+        if (kt + 1 < nk) load_frags(0, buf ^ 1, 0);
+        mfma_set(1);
+        spread();
+    }
+
+    __builtin_amdgcn_s_barrier();   // every wave is done with the stages: reuse them as epilogue slabs
+#pragma unroll
+    for (int h = 0; h < NJ / 4; ++h)
+        epilogue_rows<EPI, 8>(g, acc[h], (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * WCOLS + h * 64, lane);
+}
+
 // ---- optional in-library timing of the GEMM launches (uniform 1-in-4 sample) (HIP events on the launch stream), used by
 // bench.py for the live roofline figure.  Off by default.  Records sit in a bounded ring; when it is
 // full the oldest half (long finished) is folded into per-epilogue accumulators.
 #include <deque>
 #include <vector>
 namespace {
-constexpr int PROF_RING = 4096, PROF_EPIS = 32;   // slot = variant * 8 + epilogue id
+constexpr int PROF_RING = 4096, PROF_EPIS = 48;   // slot = variant * 8 + epilogue id (variants 1..5)
 struct ProfRec { int epi; double flops; hipEvent_t a, b; };
 bool g_prof = false;
 std::deque<ProfRec> g_recs;
@@ -504,10 +631,41 @@ static int launch_big(int epi, const GemmArgs& a, hipStream_t s) {
     return GRIP_OK;
 }
 
-// variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage), 3 = 256x128x32 (3-stage), 4 = 64x128x64 (2-stage)
+template <int NW>
+static int launch_k64(int epi, const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
+    constexpr size_t lds = (size_t)2 * 512 * BK * 2;
+    dim3 grid(tiles_m * tiles_n), block(NW * 64);
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64_kernel<E, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_k64_kernel<E, NW>), grid, block, lds, s, a, tiles_m, tiles_n);                             \
+    } break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
+        GRIP_GEMM_CASE(EPI_F16)
+        GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
+        GRIP_GEMM_CASE(EPI_F32_SCALE)
+        default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage ring), 3 = 256x128x32 (3-stage ring), 4 = 64x128x64 (2-stage),
+//          5 = 256x256x64 (2-stage, whole-line DMA)
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
+    GRIP_REQUIRE(((int64_t)a.M + 256) * a.ldc < ((int64_t)1 << 31), "gemm: output larger than 2^31 elements (M=%d ldc=%d)", a.M, a.ldc);
     const int64_t m256 = (int64_t)((a.M + 255) / 256) * 256;
     const bool can_big = a.m_pad >= m256 && a.K >= 4 * BK2;       // A must be padded to the 256-row tile
     int variant = a.variant;
@@ -527,7 +685,8 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
             if (s3 > best) { best = s3; variant = 3; }
             if (a.N % 256 == 0) {
                 const double s2 = 1.0 * fill(tm256 * (a.N / 256), 256);
-                if (s2 > best) { best = s2; variant = 2; }
+                // same tile, two feeds: the 64-wide two-stage kernel is 3-6 % faster except under the residual epilogue
+                if (s2 > best) { best = s2; variant = epi == EPI_BIAS_RESID ? 2 : 5; }
             }
         }
     }
@@ -539,6 +698,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
     if (variant == 3) {
         GRIP_REQUIRE(can_big, "gemm: 256x128 tile needs A padded to 256 rows");
         return launch_big<256, 128, 3>(epi, a, s);
+    }
+    if (variant == 5) {
+        GRIP_REQUIRE(can_big && a.N % 256 == 0 && a.K >= 2 * BK, "gemm: 256x256x64 tile needs N %% 256 == 0, K >= 128 and A padded to 256 rows");
+        return launch_k64<8>(epi, a, s);
     }
     const int bmt = variant == 4 ? 64 : 128;
     const int tiles_m = (a.M + bmt - 1) / bmt, tiles_n = a.N / BN;
