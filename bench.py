@@ -130,6 +130,16 @@ def hbm_traffic(kernel):
         return None
 
 
+def pmc_mfma_util(kernel):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (GPU cycles x 1024 SIMDs) of `kernel` from the same PMC profile (fraction of the matrix
+    pipes' cycles at the ACTUAL clock that an MFMA was executing), or None."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel.split(" [")[0]].get("mfma_util")
+    except Exception:
+        return None
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/, a port of the reference path: kind "port") on a bounded sample.
     R-mode = reference-faithful loop of utils/clip_pseudolabels.py:31-41: batch 1, the full
@@ -246,7 +256,7 @@ def main():
         "roofline": {
             "bound": "mfma", "kernel": kname(dom),
             "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-            "traffic": hbm_traffic(kname(dom)),
+            "traffic": hbm_traffic(kname(dom)), "mfma_util_pmc": pmc_mfma_util(kname(dom)),
             "launches_timed": int(launches[dom]), "avg_launch_ms": ms[dom] / max(launches[dom], 1),
             "all_gemm": {kname(i): {"launches": int(launches[i]), "ms": round(float(ms[i]), 3),
                                         "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1) if ms[i] > 0 else None}

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): rocprofv3 kernel stats of the default bench + three separate PMC passes on a short run.
+# Usage: bash tools/collect_profiles.sh <tag>   -> gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-x}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --no-cpu-baseline > $OUT/bench_line.json 2> $OUT/bench_stderr.log
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
+  N=$(echo $C | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$N -o r -- python $R/bench.py --no-cpu-baseline --pool 8800 --steps 1 --warmup 0 > /dev/null 2>> $OUT/bench_stderr.log
+  python3 - "$(find /tmp/prof_$N -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$N.csv" <<'PY'
+import csv, sys, collections
+src, dst = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(src)):
+    k = (r["Kernel_Name"], r["Counter_Name"])
+    acc[k][0] += 1
+    acc[k][1] += float(r["Counter_Value"])
+with open(dst, "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel_Name", "Counter_Name", "Launches", "Sum", "Average_per_launch"])
+    for (k, c), (n, s) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([k, c, n, s, s / n])
+PY
+done
+python $R/bench.py > $OUT/bench_line_with_cpu_baseline.json 2>> $OUT/bench_stderr.log
+ls -la $OUT
