@@ -1,5 +1,6 @@
 // Backward of the fused self-attention (input gradients only): dqkv from qkv, the saved output O
-// and dO.  One workgroup of 4 waves per (image, head); K and V of that head stay in LDS for both
+// and dO.  One workgroup of 8 waves (4 for S <= 96) per (image, head): a training batch is 16 x 12 = 192 workgroups on 256
+// CUs, so the waves inside a workgroup are the only parallelism a CU sees; K and V of that head stay in LDS for both
 // phases, probabilities are RECOMPUTED from q, k (nothing but O was saved by the forward).
 //
 //   phase 1, per 16-row query tile (wave-parallel):  S^T = K (Q/8)^T, row max / sum  -> P^T;
@@ -15,8 +16,8 @@
 
 #include "common.h"
 
-template <int KVC, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ o_saved,
+template <int KVC, bool CAUSAL, int NWB>
+__global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ o_saved,
                                                        const half_t* __restrict__ d_out, half_t* __restrict__ dqkv, int S, int H) {
     constexpr int SP = KVC * 32;
     constexpr int VST = SP + 8;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict_
     const half_t* dobase = d_out + (size_t)b * S * D + h * 64;
     half_t* dbase = dqkv + (size_t)b * S * ld + h * 64;
 
-    for (int idx = tid; idx < SP * 8; idx += 256) {
+    for (int idx = tid; idx < SP * 8; idx += NWB * 64) {
         const int row = idx >> 3, chunk = idx & 7;
         half8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
         if (row < S) {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict_
 
     const int n_qt = (S + 15) >> 4;
     // ------------------------------------------------------------------ phase 1: dQ and row statistics
-    for (int qt = wave; qt < n_qt; qt += 4) {
+    for (int qt = wave; qt < n_qt; qt += NWB) {
         asm volatile("" ::: "memory");
         const int qrow = qt * 16 + li;
         const int qr = qrow < S ? qrow : S - 1;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict_
     }
     __syncthreads();
     // ------------------------------------------------------------------ restage: T0 = (Q/8)^T, T1 = dO^T
-    for (int idx = tid; idx < SP * 8; idx += 256) {
+    for (int idx = tid; idx < SP * 8; idx += NWB * 64) {
         const int row = idx >> 3, chunk = idx & 7;
         half8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, dv = {0, 0, 0, 0, 0, 0, 0, 0};
         if (row < S) {
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict_
     __syncthreads();
     // ------------------------------------------------------------------ phase 2: dK, dV per key tile
     const int n_kt = (S + 15) >> 4;
-    for (int kt = wave; kt < n_kt; kt += 4) {
+    for (int kt = wave; kt < n_kt; kt += NWB) {
         asm volatile("" ::: "memory");
         const int kvrow = kt * 16 + li;   // this lane's key (B-operand row / output column)
         half8 kf[2], vf[2];
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict_
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) { dk[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         const int c_begin = CAUSAL ? (kt * 16) / 32 : 0;   // queries before the key tile see none of its keys
-        for (int c = c_begin; c < KVC; ++c) {
+#pragma unroll 1
+        for (int c = c_begin; c < KVC; ++c) {     // not unrolled: KVC copies of this body cost > 256 VGPRs
             half8 pf, sf;
 #pragma unroll
             for (int half_i = 0; half_i < 2; ++half_i) {
@@ -233,17 +235,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const half_t* __restrict_
     }
 }
 
-template <int KVC, bool CAUSAL>
+template <int KVC, bool CAUSAL, int NWB>
 static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, hipStream_t s) {
     constexpr int SP = KVC * 32;
     constexpr size_t lds = (size_t)2 * SP * 64 * 2 + (size_t)2 * 64 * (SP + 8) * 2 + (size_t)3 * SP * 4;
     static_assert(lds <= 160 * 1024, "attention backward tile does not fit LDS");
     static bool configured = false;
     if (!configured) {
-        GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel<KVC, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel<KVC, CAUSAL, NWB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<KVC, CAUSAL>), dim3(B * H), dim3(256), lds, s, qkv, o, d_out, dqkv, S, H);
+    hipLaunchKernelGGL((attn_bwd_kernel<KVC, CAUSAL, NWB>), dim3(B * H), dim3(NWB * 64), lds, s, qkv, o, d_out, dqkv, S, H);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
@@ -252,8 +254,8 @@ int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out
     const int kvc = (S + 31) / 32;
     GRIP_REQUIRE(S >= 1 && kvc <= 9, "attention backward: sequence length %d unsupported (max 288: K, V and their transposes of one head must fit the 160 KiB LDS)", S);
 #define GRIP_ATTN(N)                                                                        \
-    if (kvc <= N) return causal ? launch_bwd_one<N, true>(qkv, o, d_out, dqkv, B, S, H, s)  \
-                                : launch_bwd_one<N, false>(qkv, o, d_out, dqkv, B, S, H, s);
+    if (kvc <= N) return causal ? launch_bwd_one<N, true, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s)  \
+                                : launch_bwd_one<N, false, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s);
     GRIP_ATTN(1) GRIP_ATTN(2) GRIP_ATTN(3) GRIP_ATTN(4) GRIP_ATTN(5) GRIP_ATTN(6) GRIP_ATTN(7) GRIP_ATTN(8) GRIP_ATTN(9)
 #undef GRIP_ATTN
     return GRIP_ERR_ARG;
