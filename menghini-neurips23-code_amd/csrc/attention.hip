@@ -8,7 +8,7 @@
 //                          reductions are in-register + two xor-shuffles (lanes 16/32 apart).
 //   P = exp(s - max)       f32, packed to f16 in place: two score tiles form one 32-wide K chunk of
 //                          the second MFMA without any cross-lane movement.
-//   O^T = V^T P^T          A = V^T fragments, one ds_read_b128 each from a blocked LDS image of V (vt_index below),
+//   O^T = V^T P^T          A = V^T fragments, one ds_read_b128 each from a blocked LDS image of V (vt_index, common.h),
 //                          B = the packed P registers.
 //                          Each lane ends with 4 consecutive head-dim values of its own query row,
 //                          divides by its own row sum and stores 8 bytes.
@@ -18,17 +18,6 @@
 #include <stdlib.h>
 
 #include "common.h"
-
-// LDS image of V for the P.V MFMA (A operand = V^T fragment, 16 head dims x 32 keys).  Per (32-key chunk c, 16-dim block
-// nf) one 1 KiB block in which lane (li, lg) of the consuming wave finds its 8 halfs -- keys c*32 + lg*4 + {0..3} and
-// c*32 + 16 + lg*4 + {0..3} of head dim nf*16 + li -- at 16-byte unit lg*16 + (li ^ lg): one ds_read_b128 per MFMA,
-// conflict-free in the instruction's four 16-lane groups, and the staging writes (32 lanes = 32 key pairs of one dim)
-// spread over 16 banks.  (The earlier [dim][key] image needed two ds_read_b64, which the compiler fuses into a
-// ds_read2_b64: 8 LDS cycles + 2-way conflicts instead of 4.)
-__device__ __forceinline__ int vt_index(int key, int d) {
-    const int c = key >> 5, kk = key & 31, lg = (kk >> 2) & 3, e = (kk >> 4) * 4 + (kk & 3);
-    return (((c * 4 + (d >> 4)) * 64 + lg * 16 + ((d & 15) ^ lg)) * 8) + e;
-}
 
 // IEEE-754-2019 maximum: compiles to v_maximum3_f32 (two ops per four scores); fmaxf chains cost a v_max per pair plus a
 // canonicalising v_max per MFMA result.

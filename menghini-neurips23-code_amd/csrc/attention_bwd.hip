@@ -20,13 +20,12 @@ template <int KVC, bool CAUSAL, int NWB>
 __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ o_saved,
                                                        const half_t* __restrict__ d_out, half_t* __restrict__ dqkv, int S, int H) {
     constexpr int SP = KVC * 32;
-    constexpr int VST = SP + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Ks = (half_t*)smem;          // [SP][64] swizzled rows
     half_t* Vs = Ks + SP * 64;           // [SP][64] swizzled rows
-    half_t* T0 = Vs + SP * 64;           // [64][VST]: K^T in phase 1, (Q/8)^T in phase 2
-    half_t* T1 = T0 + 64 * VST;          // [64][VST]: dO^T (phase 2)
-    float* st_m = (float*)(T1 + 64 * VST);   // [SP] row max
+    half_t* T0 = Vs + SP * 64;           // blocked transposed image (vt_index): K in phase 1, Q/8 in phase 2
+    half_t* T1 = T0 + SP * 64;           // blocked transposed image of dO (phase 2)
+    float* st_m = (float*)(T1 + SP * 64);    // [SP] row max
     float* st_il = st_m + SP;                // [SP] 1 / row sum
     float* st_d = st_il + SP;                // [SP] delta
 
@@ -51,7 +50,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
         *(half8*)(Ks + row * 64 + sw) = kv;
         *(half8*)(Vs + row * 64 + sw) = vv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) T0[(chunk * 8 + j) * VST + row] = kv[j];
+        for (int j = 0; j < 8; ++j) T0[vt_index(row, chunk * 8 + j)] = kv[j];
     }
     __syncthreads();
 
@@ -131,10 +130,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                               (half_t)sc[2 * c + 1][0], (half_t)sc[2 * c + 1][1], (half_t)sc[2 * c + 1][2], (half_t)sc[2 * c + 1][3]};
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                const half_t* kp = T0 + (nf * 16 + li) * VST + c * 32 + lg * 4;
-                const half4 k0 = *(const half4*)kp;
-                const half4 k1 = *(const half4*)(kp + 16);
-                const half8 kf = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+                const half8 kf = *(const half8*)(T0 + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
                 dq[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, sf, dq[nf], 0, 0, 0);
             }
         }
@@ -159,8 +155,8 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            T0[(chunk * 8 + j) * VST + row] = qv[j];
-            T1[(chunk * 8 + j) * VST + row] = dv[j];
+            T0[vt_index(row, chunk * 8 + j)] = qv[j];
+            T1[vt_index(row, chunk * 8 + j)] = dv[j];
         }
     }
     __syncthreads();
@@ -211,15 +207,9 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
             }
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                const half_t* dp = T1 + (nf * 16 + li) * VST + c * 32 + lg * 4;
-                const half4 d0 = *(const half4*)dp;
-                const half4 d1 = *(const half4*)(dp + 16);
-                const half8 dof = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+                const half8 dof = *(const half8*)(T1 + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
                 dv[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dof, pf, dv[nf], 0, 0, 0);   // dV^T[dh][kv]
-                const half_t* qp = T0 + (nf * 16 + li) * VST + c * 32 + lg * 4;
-                const half4 q0v = *(const half4*)qp;
-                const half4 q1v = *(const half4*)(qp + 16);
-                const half8 qtf = {q0v[0], q0v[1], q0v[2], q0v[3], q1v[0], q1v[1], q1v[2], q1v[3]};
+                const half8 qtf = *(const half8*)(T0 + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
                 dk[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, sf, dk[nf], 0, 0, 0);   // dK^T[dh][kv]
             }
         }
@@ -238,7 +228,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
 template <int KVC, bool CAUSAL, int NWB>
 static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, hipStream_t s) {
     constexpr int SP = KVC * 32;
-    constexpr size_t lds = (size_t)2 * SP * 64 * 2 + (size_t)2 * 64 * (SP + 8) * 2 + (size_t)3 * SP * 4;
+    constexpr size_t lds = (size_t)4 * SP * 64 * 2 + (size_t)3 * SP * 4;
     static_assert(lds <= 160 * 1024, "attention backward tile does not fit LDS");
     static bool configured = false;
     if (!configured) {

@@ -54,6 +54,20 @@ enum GemmEpi {
     EPI_F32_SCALE = 6,       // out_f32 = acc * scalar
 };
 
+#ifdef __HIPCC__
+// LDS image of a [key][64] matrix consumed TRANSPOSED as an MFMA A operand (16 head dims x 32 keys per fragment): V in the
+// attention forward, K / Q / dO in the backward.  Per (32-key chunk c, 16-dim block
+// nf) one 1 KiB block in which lane (li, lg) of the consuming wave finds its 8 halfs -- keys c*32 + lg*4 + {0..3} and
+// c*32 + 16 + lg*4 + {0..3} of head dim nf*16 + li -- at 16-byte unit lg*16 + (li ^ lg): one ds_read_b128 per MFMA,
+// conflict-free in the instruction's four 16-lane groups, and the staging writes (32 lanes = 32 key pairs of one dim)
+// spread over 16 banks.  (The earlier [dim][key] image needed two ds_read_b64, which the compiler fuses into a
+// ds_read2_b64: 8 LDS cycles + 2-way conflicts instead of 4.)
+__device__ __forceinline__ int vt_index(int key, int d) {
+    const int c = key >> 5, kk = key & 31, lg = (kk >> 2) & 3, e = (kk >> 4) * 4 + (kk & 3);
+    return (((c * 4 + (d >> 4)) * 64 + lg * 16 + ((d & 15) ^ lg)) * 8) + e;
+}
+#endif
+
 struct GemmArgs {
     const half_t* A;    // [Mpad, K], lda = K; rows >= M may hold anything finite or not (never stored)
     const half_t* W;    // [N, K]
