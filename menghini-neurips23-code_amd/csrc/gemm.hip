@@ -15,6 +15,8 @@
 // lines (epilogue_rows).  Workgroup ids are remapped so every XCD (private 4 MiB L2) owns a contiguous run of tiles,
 // N-fastest: the A row panel and the W panel stay L2-resident across the run.  The launcher picks the tile shape by
 // (relative rate) x (fill of the last wave of workgroups).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -27,9 +29,10 @@
 // QuickGELU x * sigmoid(1.702 x) and its derivative.  v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE
 // division (ten instructions): the result is rounded to f16 right after, and at 3072 columns per token
 // the activation is a third of the c_fc GEMM's time otherwise.
-__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
+#define QGELU_C (-1.702f * 1.4426950408889634f)   // exp(-1.702 x) = exp2(QGELU_C x): one multiply in front of v_exp_f32
+__device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(QGELU_C * x)); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {
-    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(QGELU_C * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
 
@@ -42,19 +45,35 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 #define EPI_LDW 68   // slab row stride in floats: conflict-free ds_write_b128, <= 2-way ds_read_b128
 #define EPI_SLAB_FLOATS (32 * EPI_LDW)
 
+// Accumulators start at the bias (epilogues with one) instead of zero: a lane's acc[i][j] holds columns col0 + j*16 +
+// (lane>>4)*4 .. +3 of some row for every row fragment i, so four float4 loads at kernel entry replace one v_add per output
+// element in the epilogue.
+template <int EPI, int ROWFRAGS>
+__device__ __forceinline__ void init_acc(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], int col0, int lane) {
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID);
+    if constexpr (HAS_BIAS) {
+        f32x4 b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *(const f32x4*)(g.bias + col0 + j * 16 + (lane >> 4) * 4);
+#pragma unroll
+        for (int i = 0; i < ROWFRAGS; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = b[j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < ROWFRAGS; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 template <int EPI, int ROWFRAGS, bool CHECK>
 __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
     constexpr int NP = ROWFRAGS / 2;
-    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID);
     const int frow = lane & 15, fgrp = lane >> 4;
     const int rr = lane >> 4, cc = (lane & 15) * 4;
     const int col = col0 + cc;
     const int ldc = g.ldc;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (HAS_BIAS) {
-        bias4 = *(const f32x4*)(g.bias + col);
-        asm volatile("" : "+v"(bias4));   // retire the load here: a later wait for it would also drain every store issued since
-    }
     // operand prefetch (residual / GELU' argument): all 8 row loads of a pass are issued together, and
     // the loads of pass p+1 go out before the stores of pass p, so no load ever queues behind a store.
     half4 res[2][8];
@@ -96,7 +115,6 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
             f32x4 v = *(const f32x4*)(slab + rl * EPI_LDW + cc);
             const int row = row0 + p * 32 + rl;
             const uint32_t o = CHECK ? (uint32_t)row * (uint32_t)ldc + (uint32_t)col : elem_off(p, it);
-            if constexpr (HAS_BIAS) v += bias4;
             if (!CHECK || row < g.M) {
                 if constexpr (EPI == EPI_F32) {
                     *(f32x4*)((float*)g.out + o) = v;
@@ -189,10 +207,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
     }
 
     f32x4 acc[WMF][4];
-#pragma unroll
-    for (int i = 0; i < WMF; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    init_acc<EPI, WMF>(g, acc, n0 + wc * 64, lane);
 
     const int nk = g.K / BK;
     stage(0, 0);
@@ -289,10 +304,19 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     const int b_off = BMT * BK2 + (wc * 64 + frow) * BK2 + fchunk * 8;
 
     f32x4 acc[8][4];
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b = *(const f32x4*)(g.bias + n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 8; ++i) acc[i][j] = b;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     // Fragment registers are double-buffered (set 0 / set 1): while the 32 MFMAs of tile t run on one
     // set, the 12 ds_read_b128 of tile t+1 fill the other, so the LDS read phase that all waves of a
@@ -470,11 +494,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
 
     f32x4 acc[NJ / 4][8][4];
 #pragma unroll
-    for (int h = 0; h < NJ / 4; ++h)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < NJ / 4; ++h) init_acc<EPI, 8>(g, acc[h], n0 + wc * WCOLS + h * 64, lane);
 
     half8 fa[2][8], fb[2][NJ];
     auto load_frags = [&](int set, int buf, int kk) {
@@ -685,8 +705,8 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
             if (s3 > best) { best = s3; variant = 3; }
             if (a.N % 256 == 0) {
                 const double s2 = 1.0 * fill(tm256 * (a.N / 256), 256);
-                // same tile, two feeds: the 64-wide two-stage kernel is 3-6 % faster except under the residual epilogue
-                if (s2 > best) { best = s2; variant = epi == EPI_BIAS_RESID ? 2 : 5; }
+                // same tile, two feeds: the 64-wide two-stage kernel (whole-line DMA) is 2-6 % faster than the 32-wide ring
+                if (s2 > best) { best = s2; variant = (a.K >= 2 * BK && !getenv("GRIP_GEMM_RING")) ? 5 : 2; }
             }
         }
     }
