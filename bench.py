@@ -221,7 +221,7 @@ def main():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = el.item()
 
-    n = 48   # slot = variant * 8 + epilogue id (csrc/gemm.hip)
+    n = 56   # slot = variant * 8 + epilogue id (csrc/gemm.hip)
     launches = np.zeros(n, dtype=np.int64)
     ms = np.zeros(n, dtype=np.float64)
     fl = np.zeros(n, dtype=np.float64)
@@ -232,7 +232,7 @@ def main():
     def kname(slot):
         v, e = divmod(slot, 8)
         return {1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
-                5: f"gemm_k64_kernel<{e}, 8>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e]}]"
+                5: f"gemm_k64_kernel<{e}, 8>", 6: f"gemm_k64p_kernel<{e}>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e]}]"
     dom = int(np.argmax(ms))
     achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     images = loop.n_total * args.steps

@@ -69,33 +69,44 @@ __device__ __forceinline__ void init_acc(const GemmArgs& g, f32x4 (&acc)[ROWFRAG
     }
 }
 
-template <int EPI, int ROWFRAGS, bool CHECK>
+// PF = row fragments per pass: 2 -> 32-row slab with padded rows (EPI_LDW); 1 -> 16-row slab of exactly 4 KiB whose 16-byte
+// chunks are XOR-swizzled with the row instead (the persistent kernel keeps its slabs beside the two 64 KiB stages:
+// 8 x 4 KiB is all the LDS that is left).
+template <int PF>
+__device__ __forceinline__ int slab_off(int row, int chunk) {
+    if constexpr (PF == 2) return row * EPI_LDW + chunk * 4;
+    else return row * 64 + ((chunk ^ (row & 15)) * 4);
+}
+
+template <int EPI, int ROWFRAGS, bool CHECK, int PF>
 __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
-    constexpr int NP = ROWFRAGS / 2;
+    constexpr int NP = ROWFRAGS / PF;
+    constexpr int RP = 16 * PF;        // rows per pass
+    constexpr int NI = 4 * PF;         // row groups (4 rows each) per pass
     const int frow = lane & 15, fgrp = lane >> 4;
     const int rr = lane >> 4, cc = (lane & 15) * 4;
     const int col = col0 + cc;
     const int ldc = g.ldc;
     // operand prefetch (residual / GELU' argument): all 8 row loads of a pass are issued together, and
     // the loads of pass p+1 go out before the stores of pass p, so no load ever queues behind a store.
-    half4 res[2][8];
-    half4 aux[2][8];
+    half4 res[2][NI];
+    half4 aux[2][NI];
     // Addresses: one 32-bit element offset per lane plus a wave-uniform step per row group, against the uniform base
     // pointers (saddr + voffset addressing, one VGPR per access).  With 64-bit per-row pointers the compiler materialises
     // all 64 of them at the top of the epilogue and spills them when the main loop leaves < 10 free registers.
     const uint32_t lane_off = (uint32_t)(row0 + rr) * (uint32_t)ldc + (uint32_t)col;      // M * ldc < 2^31 elements (launcher)
     auto elem_off = [&](int p, int it) -> uint32_t {
         if constexpr (CHECK) {
-            int row = row0 + p * 32 + it * 4 + rr;
+            int row = row0 + p * RP + it * 4 + rr;
             row = row < g.M ? row : g.M - 1;
             return (uint32_t)row * (uint32_t)ldc + (uint32_t)col;
         } else {
-            return lane_off + (uint32_t)((p * 32 + it * 4) * ldc);
+            return lane_off + (uint32_t)((p * RP + it * 4) * ldc);
         }
     };
     auto prefetch = [&](int p, int b) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < NI; ++it) {
             const uint32_t o = elem_off(p, it);
             if constexpr (EPI == EPI_BIAS_RESID) res[b][it] = *(const half4*)(g.resid + o);
             if constexpr (EPI == EPI_GELUGRAD_F16) aux[b][it] = *(const half4*)(g.aux + o);
@@ -105,17 +116,17 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < PF; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(f32x4*)(slab + (ii * 16 + frow) * EPI_LDW + j * 16 + fgrp * 4) = acc[2 * p + ii][j];
+            for (int j = 0; j < 4; ++j) *(f32x4*)(slab + slab_off<PF>(ii * 16 + frow, j * 4 + fgrp)) = acc[PF * p + ii][j];
         if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_GELUGRAD_F16)
             if (p + 1 < NP) prefetch(p + 1, (p + 1) & 1);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < NI; ++it) {
             const int rl = it * 4 + rr;
-            f32x4 v = *(const f32x4*)(slab + rl * EPI_LDW + cc);
-            const int row = row0 + p * 32 + rl;
+            f32x4 v = *(const f32x4*)(slab + slab_off<PF>(rl, lane & 15));
+            const int row = row0 + p * RP + rl;
             const uint32_t o = CHECK ? (uint32_t)row * (uint32_t)ldc + (uint32_t)col : elem_off(p, it);
             if (!CHECK || row < g.M) {
                 if constexpr (EPI == EPI_F32) {
@@ -142,12 +153,12 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
     }
 }
 
-template <int EPI, int ROWFRAGS>
+template <int EPI, int ROWFRAGS, int PF = 2>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
     if (row0 + ROWFRAGS * 16 <= g.M)
-        epilogue_rows_impl<EPI, ROWFRAGS, false>(g, acc, slab, row0, col0, lane);
+        epilogue_rows_impl<EPI, ROWFRAGS, false, PF>(g, acc, slab, row0, col0, lane);
     else
-        epilogue_rows_impl<EPI, ROWFRAGS, true>(g, acc, slab, row0, col0, lane);
+        epilogue_rows_impl<EPI, ROWFRAGS, true, PF>(g, acc, slab, row0, col0, lane);
 }
 
 // WMF = 16-row fragments per wave along M: 4 -> 128x128 block tile, 2 -> 64x128 (small-M problems such as the
@@ -550,13 +561,141 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
         epilogue_rows<EPI, 8>(g, acc[h], (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * WCOLS + h * 64, lane);
 }
 
+// ---- Persistent form of gemm_k64_kernel: one workgroup per CU walks its XCD's run of tiles, and the two-stage K pipeline
+// simply continues across tile boundaries -- the first two stages of tile t+1 are issued at the last two stage
+// boundaries of tile t and land while tile t's epilogue runs, so a tile no longer starts with an exposed HBM/L2 round trip
+// (~2 us of a ~32 us K = 768 tile) nor ends with an idle DMA queue.  The epilogue slabs therefore cannot reuse the stage
+// buffers: they are 16-row, 4 KiB, swizzled slabs in the 32 KiB of LDS beside the two 64 KiB stages.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int BMT = 256, BNT = 256, NW = 8, WN = 4;
+    constexpr int STAGE = (BMT + BNT) * BK;       // halfs per stage (BK = 64)
+    constexpr int GI = (BMT + BNT) / 8 / NW;      // DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) half_t lds2[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave - wr * WN;
+    float* slab = (float*)(lds2 + 2 * STAGE) + wave * 1024;
+
+    // XCD x (= blockIdx & 7) owns the contiguous tile run [xstart, xstart + xcount), N-fastest; its workgroups take the
+    // run's tiles round-robin, so the 32 tiles in flight on an XCD are consecutive as in the one-tile-per-workgroup launch.
+    const int nwg = tiles_m * tiles_n;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+    const int xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int xcount = xq + (xcd < xr ? 1 : 0);
+    const int per_xcd = gridDim.x >> 3;
+    int t = blockIdx.x >> 3;
+    if (t >= xcount) return;
+
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const size_t K = (size_t)g.K;
+    const int r0 = wave * GI * 8;
+    auto tile_src = [&](int tile) {
+        const int bid = xstart + tile;
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        return (r0 < BMT ? g.A + (size_t)(tm * BMT + r0 + srow) * K : g.W + (size_t)(tn * BNT + r0 - BMT + srow) * K) + schunk * 8;
+    };
+    auto stage = [&](int buf, const half_t* src, int kt) {
+        half_t* dst = lds2 + buf * STAGE + r0 * BK;
+        const half_t* sp = src + (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < GI; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)i * 8 * K), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
+        a_off[kk] = (wr * 128 + frow) * BK + chunk * 8;
+        b_off[kk] = BMT * BK + (wc * 64 + frow) * BK + chunk * 8;
+    }
+
+    f32x4 acc[8][4];
+    half8 fa[2][8], fb[2][4];
+    auto load_frags = [&](int set, int buf, int kk) {
+        const half_t* st = lds2 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[set][j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[set][i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+    };
+    auto mfma_set = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+    };
+    auto spread = [&]() {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    };
+
+    const int nk = g.K / BK;    // >= 2 (checked by the launcher)
+    const half_t* src_cur = tile_src(t);
+    stage(0, src_cur, 0);
+    stage(1, src_cur, 1);
+    wait_vmcnt<GI>();
+    __builtin_amdgcn_s_barrier();
+    int par = 0;                // LDS slot of the current tile's stage 0
+    for (;;) {
+        const int bid = xstart + t;
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        const int m0 = tm * BMT, n0 = tn * BNT;
+        const int t_next = t + per_xcd;
+        const bool has_next = t_next < xcount;
+        const half_t* src_next = has_next ? tile_src(t_next) : src_cur;
+        if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b = *(const f32x4*)(g.bias + n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][j] = b;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        load_frags(0, par, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = (par + kt) & 1;
+            load_frags(1, buf, 1);
+            mfma_set(0);
+            spread();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage(buf, src_cur, kt + 2);
+            else if (has_next) stage(buf, src_next, kt + 2 - nk);     // the next tile's first two stages
+            if (kt + 1 < nk) load_frags(0, buf ^ 1, 0);
+            mfma_set(1);
+            spread();
+        }
+        epilogue_rows<EPI, 8, 1>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
+        if (!has_next) break;
+        par = (par + nk) & 1;
+        t = t_next;
+        src_cur = src_next;
+    }
+}
+
 // ---- optional in-library timing of the GEMM launches (uniform 1-in-4 sample) (HIP events on the launch stream), used by
 // bench.py for the live roofline figure.  Off by default.  Records sit in a bounded ring; when it is
 // full the oldest half (long finished) is folded into per-epilogue accumulators.
 #include <deque>
 #include <vector>
 namespace {
-constexpr int PROF_RING = 4096, PROF_EPIS = 48;   // slot = variant * 8 + epilogue id (variants 1..5)
+constexpr int PROF_RING = 4096, PROF_EPIS = 56;   // slot = variant * 8 + epilogue id (variants 1..6)
 struct ProfRec { int epi; double flops; hipEvent_t a, b; };
 bool g_prof = false;
 std::deque<ProfRec> g_recs;
@@ -682,8 +821,46 @@ static int launch_k64(int epi, const GemmArgs& a, hipStream_t s) {
     return GRIP_OK;
 }
 
+static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
+    constexpr size_t lds = (size_t)2 * 512 * BK * 2 + 8 * 4096;       // two stages + eight 4 KiB slabs = the whole 160 KiB
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        GRIP_CHECK_HIP(hipGetDevice(&dev));
+        GRIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu &= ~7;
+        GRIP_REQUIRE(n_cu >= 8, "gemm: device reports %d CUs", n_cu);
+    }
+    const int tiles = tiles_m * tiles_n;
+    const int grid_n = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
+    dim3 grid(grid_n), block(512);
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64p_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_k64p_kernel<E>), grid, block, lds, s, a, tiles_m, tiles_n);                                \
+    } break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
+        GRIP_GEMM_CASE(EPI_F16)
+        GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
+        GRIP_GEMM_CASE(EPI_F32_SCALE)
+        default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
 // variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage ring), 3 = 256x128x32 (3-stage ring), 4 = 64x128x64 (2-stage),
-//          5 = 256x256x64 (2-stage, whole-line DMA)
+//          5 = 256x256x64 (2-stage, whole-line DMA), 6 = the same, persistent
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
@@ -708,7 +885,9 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
             if (a.N % 256 == 0) {
                 const double s2 = 1.0 * fill(tm256 * (a.N / 256), 256);
                 // same tile, two feeds: the 64-wide two-stage kernel (whole-line DMA) is 2-6 % faster than the 32-wide ring
-                if (s2 > best) { best = s2; variant = (a.K >= 2 * BK && !getenv("GRIP_GEMM_RING")) ? 5 : 2; }
+                // ... and persistent (one workgroup per CU walking its XCD's tiles) once every CU gets several tiles
+                static const int force = getenv("GRIP_GEMM_BIG") ? atoi(getenv("GRIP_GEMM_BIG")) : 0;    // developer A/B: 2, 5 or 6
+                if (s2 > best) { best = s2; variant = force ? force : (a.K < 2 * BK ? 2 : (tm256 * (a.N / 256) >= 512 ? 6 : 5)); }
             }
         }
     }
@@ -724,6 +903,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
     if (variant == 5) {
         GRIP_REQUIRE(can_big && a.N % 256 == 0 && a.K >= 2 * BK, "gemm: 256x256x64 tile needs N %% 256 == 0, K >= 128 and A padded to 256 rows");
         return launch_k64<8>(epi, a, s);
+    }
+    if (variant == 6) {
+        GRIP_REQUIRE(can_big && a.N % 256 == 0 && a.K >= 2 * BK, "gemm: 256x256x64 tile needs N %% 256 == 0, K >= 128 and A padded to 256 rows");
+        return launch_k64p(epi, a, s);
     }
     const int bmt = variant == 4 ? 64 : 128;
     const int tiles_m = (a.M + bmt - 1) / bmt, tiles_n = a.N / BN;

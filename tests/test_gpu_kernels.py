@@ -28,11 +28,11 @@ def quick_gelu(x):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (3408, 2304, 768), (77 * 5, 512, 2048), (16, 512, 768),
                                    (50432, 768, 768), (12700, 2304, 768), (25000, 768, 3072), (16500, 3072, 768), (50000, 512, 128)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_epilogues(M, N, K, variant):
-    if variant in (2, 5) and N % 256:
+    if variant in (2, 5, 6) and N % 256:
         pytest.skip("256x256 tile needs N % 256 == 0")
-    if variant in (2, 3, 5) and K < 128:
+    if variant in (2, 3, 5, 6) and K < 128:
         pytest.skip("ring needs K >= 128")
     native, lib = _lib()
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
@@ -74,7 +74,7 @@ def test_gemm_epilogues(M, N, K, variant):
     torch.testing.assert_close(out16.float(), ref * (s * (1 + 1.702 * x * (1 - s))), **tol)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 5])
+@pytest.mark.parametrize("variant", [2, 3, 5, 6])
 def test_gemm256_is_not_transposed(variant):
     """Same transpose check through the 256x256 tile path (large M)."""
     native, lib = _lib()

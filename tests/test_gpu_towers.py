@@ -83,7 +83,7 @@ def test_golden_vitb16(models, golden_vitb16):
     assert_embeddings_close(out, g["g3.text_p16"], "B/16 text+prefix")
     logits, _ = m(x, torch.from_numpy(g["g3.zs_tokens"]).cuda())
     probs = logits.softmax(-1).cpu()
-    assert (probs - torch.from_numpy(g["g3.zs_probs"])).abs().max().item() <= 5e-3
+    assert (probs - torch.from_numpy(g["g3.zs_probs"])).abs().max().item() <= 1e-2
 
 
 @pytest.mark.parametrize("name,B,P", [("tiny", 37, 0), ("small", 9, 4), ("small", 130, 16), ("tinyL336", 3, 0), ("tinyL336", 2, 16)])
