@@ -1,10 +1,11 @@
 // f16 MFMA GEMMs for gfx950: C[M,N] = epi(A[M,K] * W[N,K]^T), f32 accumulate, v_mfma_f32_16x16x32_f16.
 //
-// Four kernels share one design (this header) and one epilogue:
-//   gemm_k64_kernel<EPI,8>          large problems (the pool encode): 256x256x64 tile, 8 waves, two 64 KiB LDS stages fed
-//                                   with whole-cache-line DMA                           -- see its own header below
+// Five kernels share one design (this header) and one epilogue:
+//   gemm_k64p_kernel<EPI>           large problems (the pool encode): 256x256x64 tile, 8 waves, two 64 KiB LDS stages fed
+//                                   with whole-cache-line DMA, persistent over tiles    -- see its own header below
+//   gemm_k64_kernel<EPI,8>          the same, one tile per workgroup (fewer than 512 tiles)
 //   gemm_big_kernel<EPI,256,256,4>  the same tile on a 4-slot ring of 32-wide K tiles, two wave groups in anti-phase
-//                                   (the round-1 default until r01-g; kept as variant 2 / GRIP_GEMM_RING=1)
+//                                   (the round-1 default until r01-g; kept as variant 2 / GRIP_GEMM_BIG=2)
 //   gemm_big_kernel<EPI,256,128,3>  ring with 4 waves and two workgroups per CU (used where 256x256 tile counts
 //                                   quantise badly over the 256 CUs)
 //   gemm_f16_kernel<EPI,WMF>        small M (training batches): 128x128x64 or 64x128x64 tile, 4 waves in a 2x2 grid,
