@@ -27,7 +27,6 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 // qf = the tile's two Q fragments (unscaled); orow = the output row pointer of this lane's query (+ head offset).
 template <int KVC, bool CAUSAL>
 __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, half8 (&qf)[2], int qrow, int S, half_t* orow, int lane) {
-    constexpr int SP = KVC * 32;
     constexpr float LOG2E = 1.4426950408889634f;
     const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
