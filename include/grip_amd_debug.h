@@ -1,0 +1,32 @@
+/* Test hooks and the in-library GEMM profiler of libgrip_amd.so.  NOT part of the drop-in ABI (include/grip_amd.h): nothing
+ * in the reference binds to these.  They exist so that tests/test_gpu_kernels.py can check each kernel against a PyTorch fp32
+ * reference through exactly the launchers the towers use, and so that bench.py can time the GEMM launches of the timed
+ * region with HIP events on the launch stream (roofline block).  All return 0 or a GRIP_ERR_* code (grip_last_error()). */
+#ifndef GRIP_AMD_DEBUG_H
+#define GRIP_AMD_DEBUG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[M,N] = epilogue(A[M,K] W[N,K]^T).  epi: 0 f32 out, 1 +bias -> f16, 2 +bias, QuickGELU -> f16 (out2 = pre-activation or
+ * NULL), 3 +bias +resid(f16) -> f16, 4 f16, 5 * QuickGELU'(aux) -> f16, 6 f32 * scalar.  A has m_pad >= M rows allocated.
+ * variant: 0 = launcher's choice, 1..6 = a specific tile kernel (csrc/gemm.hip). */
+int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid,
+                    const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream);
+/* out[B*S, H*64] = softmax(q k^T / 8 [+ causal mask]) v for qkv[B*S, 3*H*64] (f16). */
+int grip_debug_attention(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
+/* dqkv from qkv, the saved forward output o and d_out (S <= 288). */
+int grip_debug_attention_bwd(const void* qkv, const void* o, const void* d_out, void* dqkv, int B, int S, int H, int causal, void* stream);
+/* out[M,d] (f16) = LayerNorm(x[M,d] f32; gamma, beta), eps 1e-5. */
+int grip_debug_layernorm(const float* x, const float* gamma, const float* beta, void* out, int M, int d, void* stream);
+
+/* GEMM launch profiler: while enabled, every 4th GEMM launch is bracketed by HIP events on its stream. */
+int grip_profile_enable(int on);
+/* Per slot (variant * 8 + epilogue id) in [0, n): launches sampled, their total milliseconds and total 2*M*N*K. */
+int grip_profile_collect(int n, int64_t* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

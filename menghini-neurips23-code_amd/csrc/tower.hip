@@ -380,7 +380,7 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
 
 // ---------------------------------------------------------------------------------------------- test hooks
 // Kernel-level entry points for the unit parity tests (tests/test_gpu_kernels.py).  Not part of the
-// drop-in ABI (not declared in include/grip_amd.h); they launch exactly the kernels the towers use.
+// drop-in ABI (declared in include/grip_amd_debug.h, not in grip_amd.h); they launch exactly the kernels the towers use.
 extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid,
                                const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream) {
     GemmArgs a{};

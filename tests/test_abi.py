@@ -28,6 +28,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.grip_abi_version() == native.ABI_VERSION
 
 
+def test_library_exports_the_declared_test_hooks():
+    """include/grip_amd_debug.h (kernel test hooks + GEMM profiler, outside the drop-in ABI) matches the library too."""
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    text = open(os.path.join(REPO, "include", "grip_amd_debug.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(grip_[a-z_]+)\s*\(", text)))
+    assert names == sorted(native._DEBUG_SIGS), names
+    lib = native.lib()
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
 def test_layout_is_complete_and_non_overlapping():
     import numpy as np
 
