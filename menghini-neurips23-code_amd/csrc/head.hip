@@ -51,19 +51,30 @@ __global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restric
         if (lane + 64 * i < e4) v[i] = scale * (v[i] / nrm);
 
     float lg[HEAD_MAX_CV];  // lane l keeps classes l, l+64, ...
-    for (int j = 0; j < c; ++j) {
-        const f32x4* t = (const f32x4*)(txtn + (size_t)j * e);
-        float d = 0.f;
+    // Four classes per trip: their row loads and wave reductions are independent, so a wave that is alone on its SIMD (a
+    // training batch is 16 rows = 16 waves) overlaps four L2 round trips and four shuffle trees instead of one.
+    for (int j0 = 0; j0 < c; j0 += 4) {
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < HEAD_MAX_EV; ++i)
-            if (lane + 64 * i < e4) {
-                const f32x4 w = t[lane + 64 * i];
-                d += v[i][0] * w[0] + v[i][1] * w[1] + v[i][2] * w[2] + v[i][3] * w[3];
-            }
-        d = wsum(d);
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u < c ? j0 + u : c - 1;
+            const f32x4* t = (const f32x4*)(txtn + (size_t)j * e);
 #pragma unroll
-        for (int s = 0; s < HEAD_MAX_CV; ++s)
-            if ((j >> 6) == s && (j & 63) == lane) lg[s] = d;
+            for (int i = 0; i < HEAD_MAX_EV; ++i)
+                if (lane + 64 * i < e4) {
+                    const f32x4 w = t[lane + 64 * i];
+                    d[u] += v[i][0] * w[0] + v[i][1] * w[1] + v[i][2] * w[2] + v[i][3] * w[3];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = wsum(d[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+#pragma unroll
+            for (int s = 0; s < HEAD_MAX_CV; ++s)
+                if (j < c && (j >> 6) == s && (j & 63) == lane) lg[s] = d[u];
+        }
     }
     // row max + first arg-max over logits
     float m = -INFINITY;

@@ -12,6 +12,7 @@ from grip_amd import clip, rng, steps  # noqa: E402
 from grip_amd.models import CustomImageEncoder, CustomTextEncoder, ImagePrefixModel, TextPrefixModel, UPTModel  # noqa: E402
 
 dev = "cuda"
+ONLY = sys.argv[1].lower() if len(sys.argv) > 1 else ""      # "coop" | "vpt" | "upt": run just that family
 m, _ = clip.load("ViT-B/16", device=dev)
 B = 16
 x = torch.randn(B, 3, 224, 224, device=dev)
@@ -35,25 +36,34 @@ def N(name, shape, std=0.02):
     return torch.from_numpy(rng.normal(1, rng.stream_id(name), shape, 0.0, std)).to(dev)
 
 
-# CoOp
-C = 102
-classes = [f"class {i}" for i in range(C)]
-tm = TextPrefixModel(N("c", (1, 16, 512)), CustomTextEncoder(m, dev, torch.float32), classes, device=dev)
-opt = torch.optim.SGD([tm.prefix], lr=0.1, weight_decay=0.1)
-y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
-timeit("CoOp", lambda: steps.coop_step(tm, m, x, y, w, opt), B * 35.13e9 + 2 * C * 5.96e9)
-# VPT
-C = 45
-txt = m.encode_text(clip.tokenize([f"a photo of a class {i}" for i in range(C)]).to(dev))
-im = ImagePrefixModel(N("v", (16, 768)), CustomImageEncoder(m.visual), device=dev)
-opt = torch.optim.SGD([im.prefix], lr=0.1, weight_decay=0.1)
-y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
-timeit("VPT", lambda: steps.vpt_step(im, txt, scale, x, y, w, opt), 2 * B * 38.09e9)
-# UPT
-C = 47
-classes = [f"class {i}" for i in range(C)]
-um = UPTModel(N("uc", (1, 4, 512)), N("uv", (1, 4, 768)), None, CustomImageEncoder(m.visual), CustomTextEncoder(m, dev, torch.float32), classes, 128,
-              device=dev, dtype=torch.float32)
-opt = torch.optim.SGD([p for p in um.parameters() if p.requires_grad], lr=0.01, weight_decay=0.1)
-y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
-timeit("UPT", lambda: steps.upt_step(um, scale, x, y, w, opt), 2 * B * 35.87e9 + 2 * C * 5.96e9)
+def coop():
+    C = 102
+    classes = [f"class {i}" for i in range(C)]
+    tm = TextPrefixModel(N("c", (1, 16, 512)), CustomTextEncoder(m, dev, torch.float32), classes, device=dev)
+    opt = torch.optim.SGD([tm.prefix], lr=0.1, weight_decay=0.1)
+    y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
+    timeit("CoOp", lambda: steps.coop_step(tm, m, x, y, w, opt), B * 35.13e9 + 2 * C * 5.96e9)
+
+
+def vpt():
+    C = 45
+    txt = m.encode_text(clip.tokenize([f"a photo of a class {i}" for i in range(C)]).to(dev))
+    im = ImagePrefixModel(N("v", (16, 768)), CustomImageEncoder(m.visual), device=dev)
+    opt = torch.optim.SGD([im.prefix], lr=0.1, weight_decay=0.1)
+    y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
+    timeit("VPT", lambda: steps.vpt_step(im, txt, scale, x, y, w, opt), 2 * B * 38.09e9)
+
+
+def upt():
+    C = 47
+    classes = [f"class {i}" for i in range(C)]
+    um = UPTModel(N("uc", (1, 4, 512)), N("uv", (1, 4, 768)), None, CustomImageEncoder(m.visual), CustomTextEncoder(m, dev, torch.float32), classes, 128,
+                  device=dev, dtype=torch.float32)
+    opt = torch.optim.SGD([p for p in um.parameters() if p.requires_grad], lr=0.01, weight_decay=0.1)
+    y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
+    timeit("UPT", lambda: steps.upt_step(um, scale, x, y, w, opt), 2 * B * 35.87e9 + 2 * C * 5.96e9)
+
+
+for name, fn in (("coop", coop), ("vpt", vpt), ("upt", upt)):
+    if ONLY in ("", name):
+        fn()
