@@ -133,7 +133,16 @@ __global__ __launch_bounds__(256) void text_prefix_grad_kernel(const float* __re
     for (int f = lane; f < d4; f += 64) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (prefix_classes == 1) {
-            for (int c = 0; c < C; ++c) acc += ((const f32x4*)(dx + ((size_t)c * T + 1 + p) * d))[f];
+            // eight rows in flight per trip, added in class order (the sum is the same sequence of f32 adds as a plain loop)
+            int c = 0;
+            for (; c + 8 <= C; c += 8) {
+                f32x4 r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[u] = ((const f32x4*)(dx + ((size_t)(c + u) * T + 1 + p) * d))[f];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += r[u];
+            }
+            for (; c < C; ++c) acc += ((const f32x4*)(dx + ((size_t)c * T + 1 + p) * d))[f];
         } else {
             acc = ((const f32x4*)(dx + ((size_t)pc * T + 1 + p) * d))[f];
         }
