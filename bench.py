@@ -183,10 +183,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pool", type=int, default=50000, help="images per GPU (weak scaling)")
-    ap.add_argument("--chunk", type=int, default=440, help="images per encode launch: 440 x 197 rows = 339 M-tiles of 256, i.e. a near-multiple-of-256-CUs tile count for every projection")
+    ap.add_argument("--chunk", type=int, default=1320, help="images per encode launch: 1320 x 197 = 260 040 token rows = 1016 M-tiles of 256; every persistent GEMM workgroup walks >= 12 tiles (440: 20.1k img/s, 880-1760: 20.3k)")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="1: every kernel on one stream, so the per-kernel HIP-event / rocprof durations behind the roofline block are exclusive; "
-                         "2: alternate encode chunks on two streams (what pseudolabels.encode_pool does by default; +6 %% images/s, per-kernel durations overlap)")
+                         "2: alternate encode chunks on two streams (what pseudolabels.encode_pool does by default; +1 %% images/s since the GEMMs are persistent, per-kernel durations overlap)")
     ap.add_argument("--classes", type=int, default=102)
     ap.add_argument("--prefix", type=int, default=16)
     ap.add_argument("--k", type=int, default=16)

@@ -24,7 +24,7 @@ def path_ranks(paths):
 
 
 @torch.no_grad()
-def encode_pool(visual_tower, images, chunk=220, prefix=None, out=None):
+def encode_pool(visual_tower, images, chunk=880, prefix=None, out=None):
     """Encode an ordered pool.  `images` is a tensor [N,3,R,R] (any device) or a callable
     (lo, hi) -> tensor for that slice.  With torch.distributed initialised the pool is sharded
     contiguously and the embeddings are all-gathered; returns [N, E] f32 on the device."""

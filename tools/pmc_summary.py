@@ -35,7 +35,7 @@ for k, c in per.items():
 out = {
     "_how": "tools/collect_profiles.sh: three separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | "
             "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES) of `python bench.py --no-cpu-baseline --pool 8800 --steps 1 "
-            "--warmup 0` (default encode chunk 440); per-kernel averages over launches. FETCH_SIZE (KiB) is doubled per "
+            "--warmup 0` (default encode chunk 1320: ten full chunks); per-kernel averages over launches. FETCH_SIZE (KiB) is doubled per "
             "MI355X_MICROARCH.md (gfx950 tallies a wide coalesced read stream at half its bytes); mfma_util = "
             "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), i.e. against the ACTUAL shader clock "
             "(~2.05 GHz under this load, not the 2.4 GHz behind the 2.5 PF/s peak)",
