@@ -66,6 +66,49 @@ __device__ __forceinline__ int vt_index(int key, int d) {
     const int c = key >> 5, kk = key & 31, lg = (kk >> 2) & 3, e = (kk >> 4) * 4 + (kk & 3);
     return (((c * 4 + (d >> 4)) * 64 + lg * 16 + ((d & 15) ^ lg)) * 8) + e;
 }
+
+// Row-kernel helpers (rowops.hip): one wave owns a row, lane l holds float4 index l + 64*i; statistics are two in-register passes + a 6-step xor reduction.
+#define LN_EPS 1e-5f
+#define MAX_NV 8  // d <= 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 load4(const float* p, int i) { return ((const f32x4*)p)[i]; }
+__device__ __forceinline__ f32x4 load4(const half_t* p, int i) {
+    const half4 h = ((const half4*)p)[i];
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ void store4(float* p, int i, f32x4 v) { ((f32x4*)p)[i] = v; }
+__device__ __forceinline__ void store4(half_t* p, int i, f32x4 v) { ((half4*)p)[i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
+
+// The LayerNorm arithmetic is compiled with floating-point contraction OFF: it is inlined into several kernels (stand-alone,
+// gather, sequence assembly) and every one of them must round identically whatever the surrounding code lets the
+// optimiser fuse.
+template <int NV>
+__device__ __forceinline__ void ln_normalize(f32x4 (&v)[NV], int lane, int d4, int d, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            f32x4 c = v[i] - mean;
+            q += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+        }
+    rstd = rsqrtf(wave_sum(q) / (float)d + LN_EPS);
+}
+__device__ __forceinline__ f32x4 ln_apply(f32x4 v, float mean, float rstd, f32x4 g, f32x4 b) {
+#pragma clang fp contract(off)
+    return (v - mean) * rstd * g + b;
+}
 #endif
 
 struct GemmArgs {

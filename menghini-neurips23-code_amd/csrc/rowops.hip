@@ -5,40 +5,6 @@
 // 16-byte, fully coalesced access, statistics are two in-register passes + a 6-step xor reduction.
 #include "common.h"
 
-#define LN_EPS 1e-5f
-#define MAX_NV 8  // d <= 2048
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-__device__ __forceinline__ f32x4 load4(const float* p, int i) { return ((const f32x4*)p)[i]; }
-__device__ __forceinline__ f32x4 load4(const half_t* p, int i) {
-    const half4 h = ((const half4*)p)[i];
-    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-}
-__device__ __forceinline__ void store4(float* p, int i, f32x4 v) { ((f32x4*)p)[i] = v; }
-__device__ __forceinline__ void store4(half_t* p, int i, f32x4 v) { ((half4*)p)[i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
-
-template <int NV>
-__device__ __forceinline__ void ln_normalize(f32x4 (&v)[NV], int lane, int d4, int d, float& mean, float& rstd) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < d4) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    mean = wave_sum(s) / (float)d;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < d4) {
-            f32x4 c = v[i] - mean;
-            q += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
-        }
-    rstd = rsqrtf(wave_sum(q) / (float)d + LN_EPS);
-}
-
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over rows of x (residual stream, f16; or f32 for the test hook) -> f16.  row_index == null: row r reads x[r]; else row r reads
 // x[r * row_stride + row_index[r]] (EOT gather); row_stride alone gathers x[r * row_stride] (CLS).
@@ -63,7 +29,7 @@ __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, c
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
             const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], b = ((const f32x4*)beta)[lane + 64 * i];
-            const f32x4 y = (v[i] - mean) * rstd * g + b;
+            const f32x4 y = ln_apply(v[i], mean, rstd, g, b);
             o[lane + 64 * i] = (half4){(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
         }
 }
@@ -137,7 +103,7 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
             const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], bb = ((const f32x4*)beta)[lane + 64 * i];
-            store4(o, lane + 64 * i, (v[i] - mean) * rstd * g + bb);
+            store4(o, lane + 64 * i, ln_apply(v[i], mean, rstd, g, bb));
         }
 }
 
