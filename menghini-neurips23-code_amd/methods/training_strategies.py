@@ -123,13 +123,27 @@ class TrainingStrategy:
     def scale(self):
         return self.clip_model.logit_scale.exp().item()
 
-    def features(self, images, classes):
+    def frozen_image_features(self, images, names=None):
+        """Features of the FROZEN image tower.  Textual strategies re-encode the same images every epoch upstream
+        (e.g. textual_prompt.py:100: 150 epochs x the same shots); the tower is deterministic and row-independent, so the
+        features are cached per file name (`CACHE_FROZEN_FEATURES: False` restores the re-encode)."""
+        if names is None or not getattr(self.config, "CACHE_FROZEN_FEATURES", True):
+            with torch.no_grad():
+                return self.clip_model.encode_image(images)
+        cache = self.__dict__.setdefault("_frozen_cache", {})
+        miss = [i for i, n in enumerate(names) if n not in cache]
+        if miss:
+            with torch.no_grad():
+                f = self.clip_model.encode_image(images[miss])
+            for j, i in enumerate(miss):
+                cache[names[i]] = f[j]
+        return torch.stack([cache[n] for n in names])
+
+    def features(self, images, classes, names=None):
         """(image_features, text_features) of the CURRENT model, autograd-ready where prompts are involved."""
         if self.modality == "text":
             self.model.classes = classes
-            with torch.no_grad():
-                img = self.clip_model.encode_image(images)
-            return img, self.model(classes)
+            return self.frozen_image_features(images, names), self.model(classes)
         if self.modality == "image":
             return self.model(images), self.fixed_text_features(classes)
         self.model.classes = classes
@@ -203,7 +217,7 @@ class TrainingStrategy:
         total, correct, count = 0.0, 0, 0
         for i, (img, _, _, label, names) in enumerate(train_loader):
             img, label = img.to(self.device), label.to(self.device)
-            image_features, text_features = self.features(img, classes)
+            image_features, text_features = self.features(img, classes, list(names))
             logits = steps.CosineHeadFn.apply(image_features, text_features, self.scale())
             w = self.row_weights(label.tolist(), names).to(self.device)
             loss = steps.WeightedCEFn.apply(logits, lut[label], w) / accum

@@ -76,3 +76,30 @@ def test_run_main_entry_point(tmp_path):
     assert set(pickle.load(open(ev, "rb"))) == {"images", "predictions", "labels", "logits"}
     (pl,) = glob.glob(str(tmp_path / "pseudolabels" / "*.pickle"))
     assert set(pickle.load(open(pl, "rb"))) == {"filepaths", "labels"}
+
+
+def test_frozen_feature_cache_changes_nothing(tmp_path, monkeypatch):
+    """Textual strategies cache the frozen tower's image features across epochs: same prompts, bit for bit,
+    as re-encoding the images every epoch, and the tower is entered once per image instead of once per image per epoch."""
+    import grip_amd  # noqa: F401
+    from grip_amd.data import TensorPoolDataset
+    from grip_amd.methods import TextualPrompt
+    from grip_amd.methods.main import synthetic_pool
+    monkeypatch.chdir(tmp_path)
+    classes, files, images, names = synthetic_pool(4, 8, 64, 3)
+    l2i = {c: i for i, c in enumerate(classes)}
+    out = []
+    for cache in (True, False):
+        conf = _conf(MODEL="textual_prompt", LEARNING_PARADIGM="ssl", EPOCHS=3, LR=0.1, CACHE_FROZEN_FEATURES=cache)
+        data = TensorPoolDataset(files, images.cuda(), labels=names, label_map=l2i)
+        m = TextualPrompt(conf, l2i, classes, classes, classes, "cuda")
+        calls = []
+        enc = m.clip_model.encode_image
+        monkeypatch.setattr(m.clip_model, "encode_image", lambda x, _e=enc, _c=calls: (_c.append(len(x)), _e(x))[1])
+        m.define_model(classes)
+        loader = m._loader(data, True)
+        losses = [m._train_epoch(loader)[0] for _ in range(3)]
+        out.append((losses, m.unwrap_model().prefix.detach().clone(), sum(calls)))
+    (l_c, p_c, n_c), (l_r, p_r, n_r) = out
+    assert l_c == l_r and torch.equal(p_c, p_r)
+    assert n_c == len(files) and n_r == 3 * len(files)
