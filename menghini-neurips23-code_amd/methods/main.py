@@ -16,7 +16,7 @@ import yaml
 
 from .. import config as gcfg, rng
 from ..data import ImagePool, TensorPoolDataset
-from ..utils import save_parameters, save_predictions
+from ..utils import evaluate_predictions, save_parameters, save_predictions, store_results
 from . import strategies as S
 
 log = logging.getLogger(__name__)
@@ -105,6 +105,8 @@ def workflow(obj_conf, device, n_synth, n_classes=10):
     save_parameters(prompt, obj_conf)                      # methods/main_SSL.py:400
     df = model.test_predictions(test_data, standard_zsl=False)
     truth = {files[i]: names[i] for i in test_ids}
+    std_response = evaluate_predictions(obj_conf, df, [files[i] for i in test_ids], [names[i] for i in test_ids], unseen, seen)   # methods/main_SSL.py:404-414
+    store_results(obj_conf, std_response)
     acc = float(np.mean([truth[i] == c for i, c in zip(df["id"], df["class"])]))
     result = {"model": obj_conf.MODEL, "paradigm": paradigm, "encoder": obj_conf.VIS_ENCODER, "val_accuracy": val_acc, "test_accuracy": acc,
               "n_train": len(train_data), "n_unlabeled": len(unlabeled), "n_test": len(test_ids)}

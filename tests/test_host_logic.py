@@ -125,3 +125,32 @@ def test_reference_prompt_string_quirks():
     assert "f\"{template}{' '.join(i.split('_'))}\"" in src
     from grip_amd.models import CustomTextEncoder
     assert CustomTextEncoder.forward.__code__.co_varnames[:4] == ("self", "class_embeddings", "classes", "enable_pos_emb")
+
+
+def test_result_helpers_follow_the_reference_schema(tmp_path, monkeypatch):
+    """evaluate_predictions / store_results (utils/compute_metrics.py:18-103 of the reference): same return tuples and the same
+    JSON-lines file."""
+    import json
+    import types
+
+    import pandas as pd
+
+    import grip_amd  # noqa: F401
+    from grip_amd.utils import evaluate_predictions, store_results
+    monkeypatch.chdir(tmp_path)
+    files = [f"/d/{i}.jpg" for i in range(6)]
+    truth = ["a", "a", "b", "b", "c", "c"]
+    df = pd.DataFrame({"id": [f"{i}.jpg" for i in range(6)], "class": ["a", "b", "b", "b", "c", "a"]})
+    ssl = types.SimpleNamespace(LEARNING_PARADIGM="ssl", MODEL="textual_prompt", LR=0.1)
+    acc = evaluate_predictions(ssl, df, files, truth, ["a", "b", "c"], ["a", "b", "c"])
+    assert acc == (4 / 6, None, None)
+    tz = types.SimpleNamespace(LEARNING_PARADIGM="trzsl", MODEL="grip_textual", LR=0.1)
+    ua, sa, hm = evaluate_predictions(tz, df, files, truth, ["c"], ["a", "b"])
+    assert (ua, sa) == (0.5, 0.75) and abs(hm - 2 * 0.5 * 0.75 / 1.25) < 1e-12
+    store_results(ssl, acc)
+    store_results(ssl, acc)
+    store_results(tz, (ua, sa, hm))
+    lines = [json.loads(l) for l in open("results_model_textual_prompt.json")]
+    assert len(lines) == 2 and lines[0]["accuracy"] == 4 / 6 and lines[0]["model"] == "textual_prompt" and lines[0]["config"]["LR"] == 0.1
+    z = json.loads(open("results_model_grip_textual.json").read())
+    assert set(z) == {"model", "config", "harmonic_mean", "seen_accuracy", "unseen_accuracy"} and z["unseen_accuracy"] == 0.5
