@@ -93,6 +93,20 @@ def workflow(obj_conf, device, n_synth, n_classes=10):
     test_ids = sorted(test)
     test_data = sub(test_ids, False)
 
+    if obj_conf.MODEL == "clip_baseline":                  # methods/main_CLIP.py: zero-shot CLIP, nothing to train
+        from .clip_baseline import ClipBaseline
+        model = ClipBaseline(obj_conf, label_to_idx, classes, seen, unseen, device)
+        df, images_e, preds_e, logits_e = model.test_predictions(test_data)
+        truth = {files[i]: names[i] for i in test_ids}
+        std_response = evaluate_predictions(obj_conf, df, [files[i] for i in test_ids], [names[i] for i in test_ids], unseen, seen)
+        store_results(obj_conf, std_response)
+        save_predictions({"images": images_e, "predictions": preds_e, "labels": [truth[i] for i in images_e], "logits": logits_e}, obj_conf)
+        result = {"model": obj_conf.MODEL, "paradigm": paradigm, "encoder": obj_conf.VIS_ENCODER, "val_accuracy": 0.0,
+                  "test_accuracy": float(np.mean([truth[i] == c for i, c in zip(df["id"], df["class"])])),
+                  "n_train": 0, "n_unlabeled": len(unlabeled), "n_test": len(test_ids)}
+        if paradigm == "trzsl":
+            result.update(unseen_accuracy=std_response[0], seen_accuracy=std_response[1], harmonic_mean=std_response[2])
+        return result
     cls, method = MODELS[obj_conf.MODEL]
     fpl = cls.fpl
     args = (obj_conf, label_to_idx) + ((obj_conf.DATASET_DIR,) if fpl else ()) + (classes, seen, unseen, device)
@@ -120,7 +134,7 @@ def workflow(obj_conf, device, n_synth, n_classes=10):
     return result
 
 
-def main(paradigm):
+def main(paradigm, model=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--model_config", type=str, default=None, help="Name of model config file")
     parser.add_argument("--learning_paradigm", type=str, default=paradigm, help="ssl / ul / trzsl")
@@ -138,6 +152,8 @@ def main(paradigm):
                 LEARNING_PARADIGM=args.learning_paradigm)
     if isinstance(conf.get("MODEL"), str) and conf["MODEL"].startswith("$"):
         conf["MODEL"] = "textual_prompt"
+    if model:
+        conf["MODEL"] = model
     for k in ("EPOCHS", "BATCH_SIZE", "N_PSEUDOSHOTS", "STEP_QUANTILE", "N_LABEL"):
         if k in os.environ:
             conf[k] = int(os.environ[k])

@@ -103,3 +103,15 @@ def test_frozen_feature_cache_changes_nothing(tmp_path, monkeypatch):
     (l_c, p_c, n_c), (l_r, p_r, n_r) = out
     assert l_c == l_r and torch.equal(p_c, p_r)
     assert n_c == len(files) and n_r == 3 * len(files)
+
+
+def test_run_main_clip_baseline(tmp_path):
+    """run_main_clip.py: zero-shot CLIP (methods/clip_baseline.py) through the same result / evaluation files."""
+    env = dict(os.environ, VIS_ENCODER="small", PYTHONPATH=REPO)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "run_main_clip.py"), "--synthetic", "12", "--classes", "4"], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["model"] == "clip_baseline" and 0.0 <= res["test_accuracy"] <= 1.0 and res["n_test"] > 0
+    line = json.loads(open(tmp_path / "results_model_clip_baseline.json").read().splitlines()[0])
+    assert set(line) == {"model", "config", "accuracy"} and abs(line["accuracy"] - res["test_accuracy"]) < 1e-9
