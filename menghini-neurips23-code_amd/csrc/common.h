@@ -71,10 +71,21 @@ __device__ __forceinline__ int vt_index(int key, int d) {
 #define LN_EPS 1e-5f
 #define MAX_NV 8  // d <= 2048
 
+// Sum over the 64 lanes of a wave, returned in every lane, without touching the LDS: four DPP steps inside each 16-lane row
+// (xor 1, xor 2, half-mirror = the other quad, mirror = the other eight), then the four row sums are read out as scalars.
+// (__shfl_xor compiles to ds_bpermute_b32: six dependent LDS round trips per reduction, the whole cost of a row kernel
+// when a wave has a SIMD to itself.)  Needs all 64 lanes active: callers branch per wave, never per lane, before it.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+#define GRIP_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    GRIP_DPP_ADD(0xB1);     // quad_perm [1,0,3,2]
+    GRIP_DPP_ADD(0x4E);     // quad_perm [2,3,0,1]
+    GRIP_DPP_ADD(0x141);    // row_half_mirror
+    GRIP_DPP_ADD(0x140);    // row_mirror
+#undef GRIP_DPP_ADD
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ f32x4 load4(const float* p, int i) { return ((const f32x4*)p)[i]; }

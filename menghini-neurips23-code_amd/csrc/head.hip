@@ -8,11 +8,7 @@
 
 #include "common.h"
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return wave_sum(v); }
 
 // out[r] = in[r] / ||in[r]||
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int e) {

@@ -8,11 +8,7 @@
 
 #define LN_EPS 1e-5f
 
-__device__ __forceinline__ float wave_sum_b(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_sum_b(float v) { return wave_sum(v); }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
 __device__ __forceinline__ f32x4 load4b(const float* p, int i) { return ((const f32x4*)p)[i]; }
