@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of the CLIP ViT-B/16 pseudolabel + prompt-step loop on N MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+WORLD_SIZE in the environment), or plainly as `python bench.py --gpus N`, in which case it re-executes itself under
+torch.distributed.run on 127.0.0.1 (one process per GPU, RCCL = backend "nccl" on device tensors).
 
 One "step" is one full pass of the hot path over this rank's pool of synthetic images (BASELINE.json
 configs[1]: Flowers102-shaped CoOp textual-prompt SSL, C = 102 classes, 16 prompt tokens, k = 16,
@@ -13,13 +17,16 @@ ViT-B/16):
         image tower fwd, head, CE, SGD) over the M selected pseudolabeled images.
 Inputs are resident in HBM before the timed region.  Weak scaling: every rank holds --pool images.
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, live HIP-event timing inside the
-library) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1 only).
+library), `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1 only), `exact` (the fp32 comparison mode:
+images/sec and its pair overlap with the f16 lists on the same pool) and `secondary` (the other BASELINE.json
+configs: VPT step, UPT step, ViT-L/14@336px encode) -- the last two at N = 1 only, outside the timed region.
 """
 import argparse
 import ctypes
 import json
 import math
 import os
+import socket
 import sys
 import time
 
@@ -30,13 +37,21 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 import grip_amd  # noqa: E402
 from grip_amd import clip, config, dist as gdist, engine, native, pseudolabels as pl, rng, steps  # noqa: E402
-from grip_amd.models import CustomTextEncoder, TextPrefixModel  # noqa: E402
+from grip_amd.models import (CustomImageEncoder, CustomTextEncoder, ImagePrefixModel, TextPrefixModel, UPTModel)  # noqa: E402
 
 MODEL = "ViT-B/16"
 F_IMG = 35.13e9          # algorithmic FLOPs per image, frozen ViT-B/16 forward
-F_TXT = 5.96e9           # per class prompt, text tower forward
+F_TXT = 5.96e9           # per class prompt, text tower forward (77 positions)
 PEAK_F16_TFLOPS = 2500.0 # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_16x16x4_f32), the exact mode's roof
 EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE"]
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+
+
+def text_flops(seq, width=512, layers=12):
+    """FLOPs of one class prompt through the text tower when `seq` positions are encoded (QKV + out-proj + MLP = 24 S d^2,
+    attention core 4 S^2 d per layer): 5.96 GF at seq = 77; the engine encodes only positions <= the longest EOT (exact)."""
+    return layers * (24.0 * seq * width * width + 4.0 * seq * seq * width)
 
 
 def synth_tokens(C, P, seed=7):
@@ -80,20 +95,26 @@ class Loop:
         self.t_pl = self.t_tr = 0.0
         self.m_selected = 0
         self.train_steps = 0
+        self.last_lists = None
+
+    def pseudolabel_pass(self, model, streams):
+        """(i)-(iii) with `model` (the f16 engine, or the exact one for the comparison block)."""
+        a = self.args
+        with torch.no_grad():
+            txt = model.encode_text(self.zs_tokens)
+            # every rank encodes its own pool; embeddings are gathered in global (rank-major) order
+            local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
+            model.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk if model is self.m else a.exact_chunk, streams=streams)
+            emb = gdist.allgather_rows(local, self.n_total, a.pool)
+            logits, probs, am_l, am_p = engine.cosine_head(emb, txt, model.logit_scale.exp().item())
+            probs_h = probs.cpu().numpy()
+            pred_h = am_p.cpu().numpy()
+        return engine.leaderboard_scan(probs_h, pred_h, self.ranks, self.k)
 
     def step(self):
         a = self.args
         t0 = time.perf_counter()
-        with torch.no_grad():
-            txt = self.m.encode_text(self.zs_tokens)
-            # every rank encodes its own pool; embeddings are gathered in global (rank-major) order
-            local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
-            self.m.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk, streams=a.streams)
-            emb = gdist.allgather_rows(local, self.n_total, a.pool)
-            logits, probs, am_l, am_p = engine.cosine_head(emb, txt, self.m.logit_scale.exp().item())
-            probs_h = probs.cpu().numpy()
-            pred_h = am_p.cpu().numpy()
-        img, cls = engine.leaderboard_scan(probs_h, pred_h, self.ranks, self.k)
+        img, cls = self.pseudolabel_pass(self.m, a.streams)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         # (iv) prompt steps over the selected pairs that live in this rank's shard
@@ -117,34 +138,66 @@ class Loop:
         self.t_tr += t2 - t1
         self.m_selected = len(img)
         self.train_steps = n_steps
+        self.last_lists = (img, cls)
 
 
-def hbm_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected in
-    separate rocprofv3 --pmc runs of this same script; profiles/r01_traffic.json), or None."""
+# ------------------------------------------------------------------------------------------------ GEMM profiler helpers
+N_SLOTS = 56   # slot = variant * 8 + epilogue id (csrc/gemm.hip)
+
+
+def kname(slot):
+    v, e = divmod(slot, 8)
+    return {1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
+            5: f"gemm_k64_kernel<{e}, 8>", 6: f"gemm_k64p_kernel<{e}>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e]}]"
+
+
+def profile_collect(lib):
+    launches = np.zeros(N_SLOTS, dtype=np.int64)
+    ms = np.zeros(N_SLOTS, dtype=np.float64)
+    fl = np.zeros(N_SLOTS, dtype=np.float64)
+    native.check(lib.grip_profile_collect(N_SLOTS, ctypes.c_void_p(launches.ctypes.data), ctypes.c_void_p(ms.ctypes.data), ctypes.c_void_p(fl.ctypes.data)))
+    lib.grip_profile_enable(0)
+    return launches, ms, fl
+
+
+def dominant(launches, ms, fl):
+    dom = int(np.argmax(ms))
+    tf = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    return dom, tf
+
+
+def pmc_entry(kernel):
+    """Per-launch HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) and MFMA utilisation of `kernel` from the separate rocprofv3 --pmc
+    passes of this same command that are committed under profiles/ (PMC counters cannot be collected inside a timed run):
+    (bytes_per_launch, mfma_util) or (None, None)."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f)["kernels"]
-        return t[kernel.split(" [")[0]]["bytes_per_launch"]
+        with open(os.path.join(REPO, TRAFFIC_FILE)) as f:
+            t = json.load(f)["kernels"][kernel.split(" [")[0]]
+        return t.get("bytes_per_launch"), t.get("mfma_util")
     except Exception:
-        return None
+        return None, None
 
 
-def pmc_mfma_util(kernel):
-    """SQ_VALU_MFMA_BUSY_CYCLES / (GPU cycles x 1024 SIMDs) of `kernel` from the same PMC profile (fraction of the matrix
-    pipes' cycles at the ACTUAL clock that an MFMA was executing), or None."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model_string():
     try:
-        with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel.split(" [")[0]].get("mfma_util")
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args):
-    """The CPU oracle (oracle/, a port of the reference path: kind "port") on a bounded sample.
-    R-mode = reference-faithful loop of utils/clip_pseudolabels.py:31-41: batch 1, the full
-    clip_model(image, text) per image, i.e. all C class prompts re-encoded for every image.
-    B-mode (reported beside it) = batch 16 with text features cached."""
+    """The CPU oracle (oracle/, a port of the reference path: kind "port") on a bounded sample of the same workload
+    (BASELINE.md section 3).
+    R-mode = the reference loop of utils/clip_pseudolabels.py:31-41: batch 1, the full clip_model(image, text) per image, i.e.
+    the image tower at batch 1 plus all C class prompts re-encoded for every image.  The image tower is timed on every one
+    of the --cpu-sample (>= 64) images; the per-image text re-encode -- the same 102 prompts every time, ~95 % of the loop's
+    FLOPs -- is timed on --cpu-text-reps of them (full clip_model calls) and its mean is applied to the rest, which keeps
+    the default run to about a minute of CPU time instead of six.  --cpu-full times the literal loop on every image.
+    B-mode (reported beside it) = batch 16 with text features cached, averaged over >= 3 batches."""
     import importlib
     oclip = importlib.import_module("oracle.clip")
     t0 = time.perf_counter()
@@ -153,28 +206,134 @@ def cpu_baseline(args):
     C = args.classes
     tok = synth_tokens(C, 0)
     g = torch.Generator().manual_seed(1234)
-    n_r = args.cpu_sample
-    x = torch.randn(max(n_r, 16), 3, 224, 224, generator=g)
+    n_r = max(args.cpu_sample, 1)
+    reps = n_r if args.cpu_full else max(1, min(args.cpu_text_reps, n_r))
+    x = torch.randn(max(n_r, 48), 3, 224, 224, generator=g)
     with torch.no_grad():
         om(x[:1], tok[:2])   # warm-up
-        t0 = time.perf_counter()
-        for i in range(n_r):
+        t_full = []
+        for i in range(reps):            # the literal loop body: both towers + softmax + argmax
+            t0 = time.perf_counter()
             li, _ = om(x[i:i + 1], tok)
             li.softmax(dim=-1).argmax(dim=1)
-        t_r = time.perf_counter() - t0
+            t_full.append(time.perf_counter() - t0)
+        t_img = []
+        for i in range(n_r):             # the image tower at batch 1 on every sampled image
+            t0 = time.perf_counter()
+            om.encode_image(x[i:i + 1])
+            t_img.append(time.perf_counter() - t0)
+        t_text = max(float(np.mean(t_full)) - float(np.mean(t_img[:reps])), 0.0)    # the re-encode share of a full call
+        t_r = float(np.sum(t_img)) + n_r * t_text if not args.cpu_full else float(np.sum(t_full))
         t0 = time.perf_counter()
-        txt = om.encode_text(tok)
+        om.encode_text(tok)
         t_txt = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        om.encode_image(x[:16])
-        t_b = time.perf_counter() - t0
+        t_b = []
+        for b in range(3):
+            t0 = time.perf_counter()
+            om.encode_image(x[16 * b:16 * b + 16])
+            t_b.append(time.perf_counter() - t0)
+    b_ips = 16 * len(t_b) / float(np.sum(t_b))
     return {
         "value": n_r / t_r, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"R-mode (reference loop: batch 1, {C} class prompts re-encoded per image) on {n_r} images; "
-                  f"B-mode (batch 16, text cached) = {16 / t_b:.2f} images/sec, text encode {t_txt:.2f} s; "
-                  f"host cpu_count={os.cpu_count()}, oracle build {build_s:.0f} s",
-        "b_mode_images_per_sec": 16 / t_b,
+        "cpu_model": cpu_model_string(), "cpu_count": os.cpu_count(),
+        "sample": f"R-mode (reference loop: batch 1, {C} class prompts re-encoded per image) on {n_r} images: image tower timed on all {n_r} "
+                  f"({np.mean(t_img) * 1e3:.0f} ms mean), full clip_model(image, text) calls timed on {reps} of them ({np.mean(t_full):.2f} s mean) "
+                  f"and their text share applied to every image; B-mode (batch 16, text cached, {len(t_b)} batches) = {b_ips:.2f} images/sec, "
+                  f"one text encode of {C} prompts {t_txt:.2f} s; oracle build {build_s:.0f} s",
+        "r_mode_images": n_r, "r_mode_full_calls_timed": reps,
+        "b_mode_images_per_sec": b_ips, "b_mode_batches": len(t_b),
     }
+
+
+# ------------------------------------------------------------------------------------------------ exact + secondary blocks
+def exact_block(loop, lib):
+    """The fp32 comparison mode on the SAME resident pool: images/sec of its pseudolabel pass and the overlap of its
+    (image, class) pairs with the f16 engine's lists (the f16 lists differ from fp32 ones only at near-tied boundaries)."""
+    a = loop.args
+    em, _ = clip.load(MODEL, device=loop.device, exact=True)
+    # warm-up on a small slice, then one timed pass
+    with torch.no_grad():
+        em.encode_image(loop.pool[:64])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img_e, cls_e = loop.pseudolabel_pass(em, 1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    img_h, cls_h = loop.last_lists
+    pe, ph = set(zip(img_e.tolist(), cls_e.tolist())), set(zip(img_h.tolist(), cls_h.tolist()))
+    del em
+    torch.cuda.empty_cache()
+    return {"exact_images_per_sec": loop.n_total / dt, "pool_images": loop.n_total, "dtype": "f32",
+            "achieved_tflops": loop.n_total * F_IMG / dt / 1e12, "peak_tflops": PEAK_F32_TFLOPS, "frac": loop.n_total * F_IMG / dt / 1e12 / PEAK_F32_TFLOPS,
+            "pairs_exact": len(pe), "pairs_f16": len(ph), "pair_overlap_f16_vs_exact": len(pe & ph) / max(len(pe), 1),
+            "note": "f32 weights/activations/attention (v_mfma_f32_16x16x4_f32); list equality of this mode with the fp32 oracle is asserted in "
+                    "tests/test_gpu_exact.py"}
+
+
+def secondary_block(loop, lib):
+    """The other BASELINE.json configs, outside the timed region: configs[2] VPT step (RESISC45-shaped: C = 45, 16 visual prompt
+    tokens), configs[3] UPT step (DTD-shaped: C = 47, Pt = Pv = 4), configs[4] ViT-L/14@336px frozen encode (FGVCAircraft:
+    the pool encode of GRIP textual; C = 100 text-L prompts).  Each with its dominant GEMM's TFLOP/s (library HIP events)."""
+    dev, m, B = loop.device, loop.m, loop.args.batch
+    x = loop.pool[:B]
+    scale = m.logit_scale.exp().item()
+    w = torch.full((B,), 1.0 / B, device=dev)
+
+    def N(name, shape, std=0.02):
+        return torch.from_numpy(rng.normal(1, rng.stream_id(name), shape, 0.0, std)).to(dev)
+
+    def timed(fn, n, units, flops):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        lib.grip_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        launches, ms, fl = profile_collect(lib)
+        dom, tf = dominant(launches, ms, fl)
+        return {"ms": dt * 1e3, "images_per_sec": units / dt, "algorithmic_tflops": flops / dt / 1e12,
+                "dominant_kernel": kname(dom), "dominant_kernel_tflops": tf, "dominant_kernel_frac": tf / PEAK_F16_TFLOPS}
+
+    out = {}
+    C = 45
+    txt = m.encode_text(synth_tokens(C, 0, seed=8).to(dev))
+    im = ImagePrefixModel(N("v", (16, 768)), CustomImageEncoder(m.visual), device=dev)
+    opt = torch.optim.SGD([im.prefix], lr=0.1, weight_decay=0.1)
+    y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
+    out["vpt_step"] = dict(timed(lambda: steps.vpt_step(im, txt, scale, x, y, w, opt), 20, B, 2 * B * 38.09e9),
+                           workload="configs[2] RESISC45-shaped VPT step: B = 16, 16 visual prompt tokens, C = 45, ViT-B/16 fwd + dgrad bwd + SGD")
+    C = 47
+    classes = [f"class_{i}" for i in range(C)]
+    enc = CustomTextEncoder(m, dev, torch.float32)
+    enc._tok_cache[(4, tuple(classes))] = synth_tokens(C, 4, seed=9).to(dev)
+    um = UPTModel(N("uc", (1, 4, 512)), N("uv", (1, 4, 768)), None, CustomImageEncoder(m.visual), enc, classes, 128, device=dev, dtype=torch.float32)
+    opt2 = torch.optim.SGD([p for p in um.parameters() if p.requires_grad], lr=0.01, weight_decay=0.1)
+    y2 = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
+    out["upt_step"] = dict(timed(lambda: steps.upt_step(um, scale, x, y2, w, opt2), 20, B, 2 * B * 35.87e9 + 2 * C * F_TXT),
+                           workload="configs[3] DTD-shaped UPT step: B = 16, Pt = Pv = 4, C = 47, both towers fwd + bwd, mixer, SGD")
+    del im, um, opt, opt2
+    big, _ = clip.load("ViT-L/14@336px", device=dev)
+    xl = torch.randn(128, 3, 336, 336, device=dev)
+    tokl = synth_tokens(100, 0, seed=10).to(dev)
+    with torch.no_grad():
+        out["vitl14_336_encode"] = dict(timed(lambda: big.encode_image(xl), 4, 128, 128 * 381.9e9),
+                                        workload="configs[4] FGVCAircraft-shaped frozen ViT-L/14@336px encode, chunk 128 (S = 577, 24 layers, d = 1024)")
+        t = timed(lambda: big.encode_text(tokl), 5, 100, 100 * 13.30e9)
+        out["vitl14_336_encode"]["text_L_100_prompts_ms"] = t["ms"]
+    del big, xl
+    torch.cuda.empty_cache()
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -191,17 +350,34 @@ def main():
     ap.add_argument("--prefix", type=int, default=16)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--cpu-sample", type=int, default=6)
+    ap.add_argument("--cpu-sample", type=int, default=64, help="images of the R-mode CPU baseline (BASELINE.md section 3: >= 64)")
+    ap.add_argument("--cpu-text-reps", type=int, default=6, help="how many of them time the full clip_model(image, text) call (the per-image text re-encode)")
+    ap.add_argument("--cpu-full", action="store_true", help="time the literal R-mode loop on every sampled image (~6 s each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the fp32 comparison-mode block")
+    ap.add_argument("--exact-chunk", type=int, default=220)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the VPT / UPT / ViT-L/14@336px block")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run on the loopback address
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:])
+
     rank, ws = gdist.init_from_env()
-    if ws != args.gpus and not (ws == 1 and args.gpus == 1):
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if ws != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
     local_rank = gdist.local_device_index()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     lib = native.lib()
+    on_host = ws > 1 and torch.distributed.get_backend() == "gloo"
+    seen = [{"rank": rank, "device": local_rank}]
+    if ws > 1:
+        gathered = [None] * ws
+        torch.distributed.all_gather_object(gathered, seen[0])
+        seen = gathered
 
     loop = Loop(args, device, rank, ws)
     for _ in range(args.warmup):
@@ -216,26 +392,24 @@ def main():
     gdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (ws > 1 and torch.distributed.get_backend() == "gloo") else device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else device)
     if ws > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = el.item()
-
-    n = 56   # slot = variant * 8 + epilogue id (csrc/gemm.hip)
-    launches = np.zeros(n, dtype=np.int64)
-    ms = np.zeros(n, dtype=np.float64)
-    fl = np.zeros(n, dtype=np.float64)
-    native.check(lib.grip_profile_collect(n, ctypes.c_void_p(launches.ctypes.data), ctypes.c_void_p(ms.ctypes.data), ctypes.c_void_p(fl.ctypes.data)))
-    lib.grip_profile_enable(0)
+    launches, ms, fl = profile_collect(lib)
     if rank != 0:
+        if ws > 1:
+            gdist.barrier()
         return
-    def kname(slot):
-        v, e = divmod(slot, 8)
-        return {1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
-                5: f"gemm_k64_kernel<{e}, 8>", 6: f"gemm_k64p_kernel<{e}>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e]}]"
-    dom = int(np.argmax(ms))
-    achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    dom, achieved = dominant(launches, ms, fl)
     images = loop.n_total * args.steps
+    seq = int(getattr(loop.coop_tokens, "_grip_seq_len", 77) or 77)
+    seq_zs = int(loop.zs_tokens.argmax(-1).max().item()) + 1
+    train_imgs = loop.train_steps * args.batch * ws * args.steps
+    nominal = images * F_IMG + args.steps * args.classes * F_TXT * ws + args.steps * loop.train_steps * ws * (args.batch * F_IMG + 2 * args.classes * F_TXT)
+    executed = images * F_IMG + args.steps * args.classes * text_flops(seq_zs) * ws \
+        + args.steps * loop.train_steps * ws * (args.batch * F_IMG + 2 * args.classes * text_flops(seq))
+    traffic, mfma_util = pmc_entry(kname(dom))
     out = {
         "metric": "images/sec CLIP ViT-B/16 encode+prompt-step",
         "value": images / elapsed,
@@ -248,24 +422,43 @@ def main():
                    "pool_images_per_gpu": args.pool, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
                    "encode_chunk": args.chunk, "encode_streams": args.streams, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
                    "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps),
-                   "text_positions_encoded": int(getattr(loop.coop_tokens, "_grip_seq_len", 77) or 77)},
+                   "text_positions_encoded": seq,
+                   "train_sharding": "each rank steps on the selected images of its OWN shard (zero-weight rows where it owns none), batch 16 per rank; "
+                                     "prompt gradients are mean-all-reduced every step -- not one global batch split over ranks",
+                   "collectives": "RCCL all_gather_into_tensor of [pool, 512] f32 embeddings per pass + all_reduce of the 32 KB prompt gradient per step"
+                                  if not on_host else "gloo through host memory (GRIP_DIST_BACKEND=gloo)"},
+        "ranks_seen": seen,
         "pseudolabel_images_per_sec": images / loop.t_pl if loop.t_pl else None,
-        "train_images_per_sec": (loop.train_steps * args.batch * ws * args.steps) / loop.t_tr if loop.t_tr else None,
-        "algorithmic_tflops": (images * F_IMG + args.steps * args.classes * F_TXT
-                               + args.steps * loop.train_steps * ws * (args.batch * F_IMG + 2 * args.classes * F_TXT)) / elapsed / 1e12 / ws,
+        "train_images_per_sec": train_imgs / loop.t_tr if loop.t_tr else None,
+        "algorithmic_tflops": nominal / elapsed / 1e12 / ws,
+        "executed_tflops": executed / elapsed / 1e12 / ws,
+        "flops_note": "per GPU; algorithmic = BASELINE.md section 2 (77 text positions per prompt); executed = the same with the text tower's "
+                      f"{seq_zs} (zero-shot) / {seq} (CoOp) encoded positions (positions after the last EOT cannot influence any output)",
         "roofline": {
             "bound": "mfma", "kernel": kname(dom),
             "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-            "traffic": hbm_traffic(kname(dom)), "mfma_util_pmc": pmc_mfma_util(kname(dom)),
+            "traffic": traffic, "mfma_util_pmc": mfma_util,
+            "traffic_source": f"{TRAFFIC_FILE}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES), "
+                              "read from the committed file, not measured in this run",
             "launches_timed": int(launches[dom]), "avg_launch_ms": ms[dom] / max(launches[dom], 1),
             "all_gemm": {kname(i): {"launches": int(launches[i]), "ms": round(float(ms[i]), 3),
                                         "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1) if ms[i] > 0 else None}
-                         for i in range(n) if launches[i]},
+                         for i in range(N_SLOTS) if launches[i]},
         },
     }
-    if ws == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
+    if ws == 1:
+        if not args.no_exact:
+            out["exact"] = exact_block(loop, lib)
+        if not args.no_secondary:
+            del loop.pool
+            loop.pool = synth_pool(64, loop.d.image_resolution, device, 99)
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_block(loop, lib)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out), flush=True)
+    if ws > 1:
+        gdist.barrier()
 
 
 if __name__ == "__main__":

@@ -13,7 +13,8 @@
  * grip_tower_create.  Device pointers are plain pointers into HBM (torch tensors' data_ptr()).
  *
  * Dtypes: GEMM operands and the residual stream f16 (MFMA v_mfma_f32_16x16x32_f16, f32 accumulate, adds into the
- * stream in f32); LayerNorm statistics, softmax, head, embeddings and gradients f32.
+ * stream in f32); LayerNorm statistics, softmax, head, embeddings and gradients f32.  A tower created with
+ * dims.precision = 1 computes everything in f32 instead (exact comparison mode, inference only).
  */
 #ifndef GRIP_AMD_H
 #define GRIP_AMD_H
@@ -36,7 +37,7 @@ typedef enum {
 const char* grip_last_error(void);
 /* ABI version of this header; the host layer refuses a library that reports another one. */
 int grip_abi_version(void);
-#define GRIP_ABI_VERSION 2
+#define GRIP_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------------------------
  * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
@@ -54,6 +55,10 @@ typedef struct {
     int32_t resolution;  /* vision: input resolution; text: 0 */
     int32_t vocab;       /* text: vocabulary size; vision: 0 */
     int32_t max_prefix;  /* largest number of prompt tokens any call will use (sizes nothing but checks) */
+    int32_t precision;   /* 0 = f16 GEMM operands + f16 residual stream (what clip.load gives the reference on a GPU);
+                            1 = exact comparison mode: f32 weights, activations, residual stream and attention
+                            (v_mfma_f32_16x16x4_f32), i.e. the arithmetic of the reference's CPU path (clip.load(..., "cpu")
+                            keeps fp32).  Inference only: train != 0 is GRIP_ERR_ARG on a precision-1 tower. */
 } grip_dims;
 
 /* Weight layout.  A tower's frozen weights live in two caller-owned device blobs: one f16 (GEMM
@@ -64,7 +69,7 @@ typedef struct {
  * written by grip_tower_finalize).  Returns GRIP_OK, or GRIP_ERR_ARG when `slot` is past the end. */
 typedef struct {
     char name[96];
-    int32_t dtype;      /* 0 = f16 blob, 1 = f32 blob */
+    int32_t dtype;      /* 0 = GEMM-operand blob (f16; f32 elements when dims.precision = 1), 1 = f32 blob */
     int32_t derived;    /* 1 = written by grip_tower_finalize */
     int64_t offset;     /* element offset inside its blob (16-byte aligned) */
     int64_t rows;       /* logical shape rows x cols, row-major */
@@ -77,7 +82,8 @@ int grip_layout_size(const grip_dims* dims, int64_t* n_f16, int64_t* n_f32);
 
 typedef struct grip_tower grip_tower;
 
-/* Replaces clip.load's module construction for one tower.  Blobs must outlive the handle. */
+/* Replaces clip.load's module construction for one tower.  Blobs must outlive the handle.  `f16_blob` is the GEMM-operand
+ * blob of n_f16 ELEMENTS: f16, or f32 when dims.precision = 1. */
 int grip_tower_create(const grip_dims* dims, void* f16_blob, void* f32_blob, grip_tower** out);
 /* Builds derived weights (transposed copies) on `stream`; call after the primary slots are filled
  * and again whenever they change. */
@@ -96,15 +102,18 @@ int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int seq_l
  *   prefix     [n_prefix, width] f32, or NULL when n_prefix == 0; inserted between CLS and the
  *              patches after the positional embedding, shared by the whole batch
  *   out_emb    [batch, embed_dim] f32 (un-normalised, as the reference returns it)
+ *   generation NULL, or receives the number of this train-mode forward (0 for train = 0).  Several train-mode forwards may
+ *              be outstanding, each on its own workspace; a second one on the SAME workspace overwrites the first one's
+ *              saved activations, and a backward that presents the first one's number then fails with GRIP_ERR_STATE.
  */
 int grip_vit_forward(grip_tower* t, const void* images, int images_f16, const float* prefix, int n_prefix,
-                     int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, void* stream);
+                     int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream);
 
 /* Input-gradient chain of the frozen ViT down to the prompt slice (autograd of the above w.r.t.
  * image_prefix only; no weight gradients exist).  Must follow a train-mode forward on the same
- * workspace.  grad_emb [batch, embed_dim] f32 -> grad_prefix [n_prefix, width] f32 (summed over batch). */
+ * workspace, exactly once per forward; generation = the number that forward returned (0 = do not check).  grad_emb [batch, embed_dim] f32 -> grad_prefix [n_prefix, width] f32 (summed over batch). */
 int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* prefix, float* grad_prefix,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             void* workspace, size_t workspace_bytes, uint64_t generation, void* stream);
 
 /* CustomTextEncoder.forward(class_embeddings, classes) / clip_model.encode_text(tokens)
  * (models/clip_encoders.py:43-90; :13-22 with n_prefix = 0).  Tokenisation stays on the host.
@@ -118,12 +127,12 @@ int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* 
  */
 int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
                       int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
-                      void* workspace, size_t workspace_bytes, int train, void* stream);
+                      void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream);
 
 /* grad_emb [n_class, embed_dim] -> grad_prefix [prefix_classes, n_prefix, width] (summed over classes
  * when prefix_classes == 1). */
 int grip_text_backward_prefix(grip_tower* t, const float* grad_emb, float* grad_prefix,
-                              void* workspace, size_t workspace_bytes, void* stream);
+                              void* workspace, size_t workspace_bytes, uint64_t generation, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cosine x logit-scale head + softmax + argmax: the block inlined 45 times in the reference, e.g.

@@ -11,11 +11,14 @@ extern "C" {
 
 /* out[M,N] = epilogue(A[M,K] W[N,K]^T).  epi: 0 f32 out, 1 +bias -> f16, 2 +bias, QuickGELU -> f16 (out2 = pre-activation or
  * NULL), 3 +bias +resid(f16) -> f16, 4 f16, 5 * QuickGELU'(aux) -> f16, 6 f32 * scalar.  A has m_pad >= M rows allocated.
- * variant: 0 = launcher's choice, 1..6 = a specific tile kernel (csrc/gemm.hip). */
+ * variant: 0 = launcher's choice, 1..6 = a specific tile kernel (csrc/gemm.hip); 7 = the exact-mode kernel (csrc/gemm_f32.hip):
+ * A, W, resid and every output are f32 (epi 0..3 and 6 only). */
 int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid,
                     const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream);
 /* out[B*S, H*64] = softmax(q k^T / 8 [+ causal mask]) v for qkv[B*S, 3*H*64] (f16). */
 int grip_debug_attention(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
+/* The same in f32 (exact mode, csrc/attention_f32.hip): qkv and out f32, any S. */
+int grip_debug_attention_exact(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
 /* dqkv from qkv, the saved forward output o and d_out (S <= 288). */
 int grip_debug_attention_bwd(const void* qkv, const void* o, const void* d_out, void* dqkv, int B, int S, int H, int causal, void* stream);
 /* out[M,d] (f16) = LayerNorm(x[M,d] f32; gamma, beta), eps 1e-5. */

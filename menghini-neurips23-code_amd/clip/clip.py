@@ -1,5 +1,6 @@
 """`clip.load` / `clip.tokenize` of the native engine (same call signatures as openai-CLIP's)."""
 import hashlib
+import logging
 import os
 import re
 
@@ -8,6 +9,17 @@ import torch
 from .. import config as _cfg, weights as _weights
 from . import model  # noqa: F401
 from .model import CLIP
+
+log = logging.getLogger(__name__)
+_WARNED = set()
+PROVENANCE = {"weights": None, "tokenizer": None}   # what the last clip.load / clip.tokenize actually used (stored with results)
+
+
+def _warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        log.warning(msg)
+
 
 _WORD = re.compile(r"[a-z]+|[0-9]|[^\sa-z0-9]+")
 
@@ -20,6 +32,7 @@ def _word_id(w: str) -> int:
 
 
 _TOKENIZER = None
+_SD_CACHE = {}
 
 
 def _bpe():
@@ -40,6 +53,13 @@ def tokenize(texts, context_length: int = 77, truncate: bool = False):
     if isinstance(texts, str):
         texts = [texts]
     tk = _bpe()
+    if tk is None:
+        if os.environ.get("CLIP_WEIGHTS"):
+            raise RuntimeError("CLIP_WEIGHTS is set but no BPE vocabulary is available ($CLIP_BPE_VOCAB): the stand-in word-hash "
+                               "tokenizer would index a real token_embedding with meaningless ids")
+        _warn_once("tok", "clip.tokenize: no BPE vocabulary ($CLIP_BPE_VOCAB) -- using the STAND-IN word-hash tokenizer; "
+                          "text features are only meaningful together with the synthetic weights")
+    PROVENANCE["tokenizer"] = "bpe" if tk is not None else "stand-in"
     out = torch.zeros(len(texts), context_length, dtype=torch.int)
     for i, t in enumerate(texts):
         if tk is not None:
@@ -66,17 +86,27 @@ def _preprocess(n_px, device):
     return ClipPreprocess(n_px, device)
 
 
-def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0):
+def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0, exact=None):
     """(model, preprocess).  Weights: $CLIP_WEIGHTS (a torch-saved OpenAI state_dict) when set,
-    else the seeded synthetic init of grip_amd.weights (no checkpoints exist offline)."""
+    else the seeded synthetic init of grip_amd.weights (no checkpoints exist offline).
+    exact=True (or GRIP_EXACT=1): f32 towers -- weights, activations, attention and residual stream in fp32, the
+    arithmetic the reference's CPU path uses (clip.load(..., device="cpu") keeps fp32) -- for index-exact comparison of
+    the pseudolabel lists; inference only, ~1/10 of the f16 throughput."""
     d = _cfg.get_dims(name)
-    m = CLIP(d, device)
+    if exact is None:
+        exact = os.environ.get("GRIP_EXACT", "0") == "1"
+    m = CLIP(d, device, exact=exact)
     path = os.environ.get("CLIP_WEIGHTS")
     if path:
         sd = torch.load(path, map_location="cpu")
         sd = sd.get("state_dict", sd)
+        PROVENANCE["weights"] = path
     else:
-        sd = {k: torch.from_numpy(v) for k, v in _weights.init_state_dict(d, seed).items()}
+        _warn_once("weights", "clip.load: no $CLIP_WEIGHTS -- using SYNTHETIC seeded random-init weights (accuracies are meaningless)")
+        PROVENANCE["weights"] = "synthetic"
+        if _SD_CACHE.get("key") != (name, seed):      # a second load of the same synthetic model (e.g. its exact twin) reuses the arrays
+            _SD_CACHE.update(key=(name, seed), sd=_weights.init_state_dict(d, seed))
+        sd = {k: torch.from_numpy(v) for k, v in _SD_CACHE["sd"].items()}
     load_openai_state_dict(m, sd)
     return m, _preprocess(d.image_resolution, device)
 

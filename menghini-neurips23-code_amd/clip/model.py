@@ -58,11 +58,11 @@ class _TowerModule(nn.Module):
 class VisionTransformer(_TowerModule):
     """clip_model.visual: frozen ViT on the native vision tower."""
 
-    def __init__(self, d: ClipDims, device):
+    def __init__(self, d: ClipDims, device, exact=False):
         super().__init__()
         self.input_resolution = d.image_resolution
         self.output_dim = d.embed_dim
-        self._bind(engine.vision_tower(d, device))
+        self._bind(engine.vision_tower(d, device, exact=exact))
 
     def forward(self, x: torch.Tensor, prefix=None):
         return self.tower.vit_forward(x, prefix)[0]
@@ -107,14 +107,15 @@ class Transformer(nn.Module):
 
 
 class CLIP(_TowerModule):
-    def __init__(self, d: ClipDims, device="cuda"):
+    def __init__(self, d: ClipDims, device="cuda", exact=False):
         super().__init__()
         self.dims = d
+        self.exact = bool(exact)   # f32 towers (comparison mode): `dtype` is float32, like the reference's clip.load on a CPU
         self.context_length = d.context_length
         self.vocab_size = d.vocab_size
-        self.visual = VisionTransformer(d, device)
+        self.visual = VisionTransformer(d, device, exact=exact)
         self.add_module("token_embedding", _Embedding())
-        self._bind(engine.text_tower(d, device))
+        self._bind(engine.text_tower(d, device, exact=exact))
         self.logit_scale = _frozen(torch.ones([], device=device) * math.log(1 / 0.07))
 
     @property

@@ -1,0 +1,98 @@
+// Exact-mode multi-head self-attention, all f32 on the vector ALUs (head dim 64): the comparison mode's counterpart of
+// attention.hip.  softmax(Q K^T / 8) V per (image, head) exactly as nn.MultiheadAttention computes it in the published
+// openai/CLIP ResidualAttentionBlock (q scaled by 1/8 before the product, additive -inf causal mask in the text tower),
+// with the running-maximum form of the softmax so any sequence length works from 16 KiB of LDS.
+//
+// One thread owns one query row: its 64 q values and 64 output accumulators live in registers; the keys / values of the
+// head stream through LDS 32 rows at a time and are read as wave-wide broadcasts (every lane the same address, one LDS
+// cycle group per ds_read_b128).  Per tile: 32 scores, tile maximum, one rescale of the accumulators, 32 exp, P.V.
+// Throughput is bounded by the LDS broadcast reads (32 ds_read_b128 per key per wave); the attention core is 4 % of the
+// tower's FLOPs and this path exists for bit-level comparison, not speed.
+#include <math.h>
+
+#include "common.h"
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int H, int qblocks) {
+    __shared__ f32x4 Ks[32][16];
+    __shared__ f32x4 Vs[32][16];
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x - bh * qblocks;
+    const int b = bh / H, h = bh - b * H;
+    const int D = H * 64;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * S * ld + h * 64;
+    const int qi = qb * 256 + tid;
+    const int qr = qi < S ? qi : S - 1;
+
+    f32x4 q[16], o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        q[c] = ((const f32x4*)(base + (size_t)qr * ld))[c] * 0.125f;   // 1/sqrt(64), exact
+        o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float m = -INFINITY, l = 0.f;
+    const int kend = CAUSAL ? (qb * 256 + 256 < S ? qb * 256 + 256 : S) : S;   // keys any query of this block can see
+    for (int k0 = 0; k0 < kend; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = (tid >> 4) + rr * 16, c = tid & 15, key = k0 + r;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < S) {
+                kv = ((const f32x4*)(base + (size_t)key * ld + D))[c];
+                vv = ((const f32x4*)(base + (size_t)key * ld + 2 * D))[c];
+            }
+            Ks[r][c] = kv;
+            Vs[r][c] = vv;
+        }
+        __syncthreads();
+        float s[32];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 kf = Ks[j][c];
+                a = fmaf(q[c][0], kf[0], a); a = fmaf(q[c][1], kf[1], a); a = fmaf(q[c][2], kf[2], a); a = fmaf(q[c][3], kf[3], a);
+            }
+            const int key = k0 + j;
+            if (key >= S || (CAUSAL && key > qi)) a = -INFINITY;
+            s[j] = a;
+            tmax = fmaxf(tmax, a);
+        }
+        const float mn = fmaxf(m, tmax);          // finite from the first tile on: key 0 is visible to every query
+        const float corr = expf(m - mn);          // exp(-inf) = 0 on the first tile
+        l *= corr;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) o[c] = o[c] * corr;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float p = expf(s[j] - mn);
+            l += p;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 vf = Vs[j][c];
+                o[c][0] = fmaf(p, vf[0], o[c][0]); o[c][1] = fmaf(p, vf[1], o[c][1]); o[c][2] = fmaf(p, vf[2], o[c][2]); o[c][3] = fmaf(p, vf[3], o[c][3]);
+            }
+        }
+        m = mn;
+    }
+    if (qi < S) {
+        f32x4* op = (f32x4*)(out + ((size_t)b * S + qi) * D + h * 64);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) op[c] = o[c] / l;
+    }
+}
+
+int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s) {
+    GRIP_REQUIRE(S >= 1 && B >= 1 && H >= 1, "attention_f32: bad shape B=%d S=%d H=%d", B, S, H);
+    const int qblocks = (S + 255) / 256;
+    if (causal)
+        hipLaunchKernelGGL(attn_fwd_f32_kernel<true>, dim3(B * H * qblocks), dim3(256), 0, s, qkv, out, S, H, qblocks);
+    else
+        hipLaunchKernelGGL(attn_fwd_f32_kernel<false>, dim3(B * H * qblocks), dim3(256), 0, s, qkv, out, S, H, qblocks);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

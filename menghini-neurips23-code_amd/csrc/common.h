@@ -123,35 +123,39 @@ __device__ __forceinline__ f32x4 ln_apply(f32x4 v, float mean, float rstd, f32x4
 #endif
 
 struct GemmArgs {
-    const half_t* A;    // [Mpad, K], lda = K; rows >= M may hold anything finite or not (never stored)
-    const half_t* W;    // [N, K]
+    const void* A;      // [Mpad, K], lda = K; rows >= M may hold anything finite or not (never stored).  f16, or f32 when f32 != 0
+    const void* W;      // [N, K], same element type as A
     int M, N, K;
     int variant;        // 0 = let the launcher choose the tile shape; 1/2/3 force 128x128 / 256x256 / 256x128 (tests, tuning)
     int64_t m_pad;      // rows allocated for A (>= M); the 256-row tile is used only when m_pad covers it
     const float* bias;  // [N] or null
-    const resid_t* resid; // [M, ldc] residual stream (EPI_BIAS_RESID)
-    const half_t* aux;  // [M, ldc] f16 (EPI_GELUGRAD_F16)
-    void* out;          // [M, ldc] f16 or f32
+    const void* resid;  // [M, ldc] residual stream (EPI_BIAS_RESID), activation type
+    const void* aux;    // [M, ldc] activation type (EPI_GELUGRAD_F16)
+    void* out;          // [M, ldc] activation type or f32
     void* out2;         // optional second output
     int ldc;
     float scalar;
+    int f32;            // 1 = exact mode: A, W, resid and every activation output are f32 (gemm_f32.hip, v_mfma_f32_16x16x4_f32)
 };
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
+int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);
 
+// Activation buffers are f16 (default) or f32 (exact mode): the row kernels take untyped pointers plus the flag.
 // row-wise kernels (rowops.hip)
-int launch_im2col(const void* images, int images_f16, half_t* out, int B, int R, int patch, int Kpad, hipStream_t s);
+int launch_im2col(const void* images, int images_f16, void* out, int out_f32, int B, int R, int patch, int Kpad, hipStream_t s);
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, resid_t* x, int B, int G2, int d, hipStream_t s);
-int launch_layernorm_f16(const resid_t* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
-int launch_gather_ln_f16(const resid_t* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
-                         half_t* out, int n_rows, int d, hipStream_t s);
+                           const float* gamma, const float* beta, void* x, int f32, int B, int G2, int d, hipStream_t s);
+int launch_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int f32, int M, int d, hipStream_t s);
+int launch_gather_ln_f16(const void* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
+                         void* out, int f32, int n_rows, int d, hipStream_t s);
 int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, resid_t* x, int C, int T, int d, int vocab, hipStream_t s);
-int launch_transpose_f16(const half_t* in, half_t* out, int rows, int cols, int ld_in, hipStream_t s);
+                      int prefix_classes, void* x, int f32, int C, int T, int d, int vocab, hipStream_t s);
+int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int ld_in, hipStream_t s);
 
-// attention (attention.hip): qkv [B*S, 3*D] f16 -> out [B*S, D] f16
+// attention (attention.hip / attention_f32.hip): qkv [B*S, 3*D] -> out [B*S, D]
 int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s);
+int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s);
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
 // backward row kernels (rowops_bwd.hip)
 int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);

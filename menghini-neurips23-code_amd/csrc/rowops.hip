@@ -8,10 +8,10 @@
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over rows of x (residual stream, f16; or f32 for the test hook) -> f16.  row_index == null: row r reads x[r]; else row r reads
 // x[r * row_stride + row_index[r]] (EOT gather); row_stride alone gathers x[r * row_stride] (CLS).
-template <int NV, typename XT>
+template <int NV, typename XT, typename OT = half_t>
 __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     half_t* __restrict__ out, int n_rows, int d) {
+                                                     OT* __restrict__ out, int n_rows, int d) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -24,13 +24,12 @@ __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, c
         if (lane + 64 * i < d4) v[i] = load4(xr, lane + 64 * i);
     float mean, rstd;
     ln_normalize<NV>(v, lane, d4, d, mean, rstd);
-    half4* o = (half4*)(out + (size_t)row * d);
+    OT* o = out + (size_t)row * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
             const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], b = ((const f32x4*)beta)[lane + 64 * i];
-            const f32x4 y = ln_apply(v[i], mean, rstd, g, b);
-            o[lane + 64 * i] = (half4){(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+            store4(o, lane + 64 * i, ln_apply(v[i], mean, rstd, g, b));
         }
 }
 
@@ -48,8 +47,12 @@ __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, c
         }                                                                                      \
     } while (0)
 
-int launch_layernorm_f16(const resid_t* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s) {
-    DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, resid_t>), dim3((M + 3) / 4), dim3(256), 0, s, x, (const int32_t*)nullptr, 1, gamma, beta, out, M, d));
+int launch_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int f32, int M, int d, hipStream_t s) {
+    if (f32) {
+        DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, float, float>), dim3((M + 3) / 4), dim3(256), 0, s, (const float*)x, (const int32_t*)nullptr, 1, gamma, beta, (float*)out, M, d));
+    } else {
+        DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, resid_t>), dim3((M + 3) / 4), dim3(256), 0, s, (const resid_t*)x, (const int32_t*)nullptr, 1, gamma, beta, (half_t*)out, M, d));
+    }
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
@@ -60,9 +63,13 @@ int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const floa
     return GRIP_OK;
 }
 
-int launch_gather_ln_f16(const resid_t* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
-                         half_t* out, int n_rows, int d, hipStream_t s) {
-    DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, resid_t>), dim3((n_rows + 3) / 4), dim3(256), 0, s, x, row_index, row_stride, gamma, beta, out, n_rows, d));
+int launch_gather_ln_f16(const void* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
+                         void* out, int f32, int n_rows, int d, hipStream_t s) {
+    if (f32) {
+        DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, float, float>), dim3((n_rows + 3) / 4), dim3(256), 0, s, (const float*)x, row_index, row_stride, gamma, beta, (float*)out, n_rows, d));
+    } else {
+        DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, resid_t>), dim3((n_rows + 3) / 4), dim3(256), 0, s, (const resid_t*)x, row_index, row_stride, gamma, beta, (half_t*)out, n_rows, d));
+    }
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
@@ -73,11 +80,11 @@ int launch_gather_ln_f16(const resid_t* x, const int32_t* row_index, int row_str
 //   row (b, 1..P)         = prefix[s-1]                         (no positional embedding)
 //   row (b, 1+P+j)        = patch_out[b*G2 + j] + pos[1+j]
 // then LayerNorm -> x (residual stream), S = 1 + P + G2.
-template <int NV>
+template <int NV, typename RT>
 __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ prefix, int P,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              resid_t* __restrict__ x, int B, int G2, int d) {
+                                                              RT* __restrict__ x, int B, int G2, int d) {
     const int lane = threadIdx.x & 63;
     const int S = 1 + P + G2;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
         }
     float mean, rstd;
     ln_normalize<NV>(v, lane, d4, d, mean, rstd);
-    resid_t* o = x + (size_t)row * d;
+    RT* o = x + (size_t)row * d;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
@@ -108,18 +115,23 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
 }
 
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, resid_t* x, int B, int G2, int d, hipStream_t s) {
+                           const float* gamma, const float* beta, void* x, int f32, int B, int G2, int d, hipStream_t s) {
     const int rows = B * (1 + P + G2);
-    DISPATCH_NV(d, hipLaunchKernelGGL(vit_assemble_ln_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, x, B, G2, d));
+    if (f32) {
+        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, float>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (float*)x, B, G2, d));
+    } else {
+        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, resid_t>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (resid_t*)x, B, G2, d));
+    }
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Text embedding (models/clip_encoders.py:63-74): x[c, t] = (1 <= t <= P ? prefix[c or 0, t-1] : tok_emb[ids[c, t]]) + pos[t]
+template <typename RT>
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, int ld_ids, const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, const float* __restrict__ prefix, int P,
-                                                         int prefix_classes, resid_t* __restrict__ x, int C, int T, int d, int vocab) {
+                                                         int prefix_classes, RT* __restrict__ x, int C, int T, int d, int vocab) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= C * T) return;
@@ -134,14 +146,17 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
         src = (const f32x4*)(tok_emb + (size_t)id * d);
     }
     const f32x4* pp = (const f32x4*)(pos + (size_t)t * d);
-    resid_t* o = x + (size_t)row * d;
+    RT* o = x + (size_t)row * d;
     for (int f = lane; f < d4; f += 64) store4(o, f, src[f] + pp[f]);
 }
 
 int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, resid_t* x, int C, int T, int d, int vocab, hipStream_t s) {
+                      int prefix_classes, void* x, int f32, int C, int T, int d, int vocab, hipStream_t s) {
     GRIP_REQUIRE(d % 4 == 0, "text_embed: width %% 4 != 0");
-    hipLaunchKernelGGL(text_embed_kernel, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, x, C, T, d, vocab);
+    if (f32)
+        hipLaunchKernelGGL(text_embed_kernel<float>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (float*)x, C, T, d, vocab);
+    else
+        hipLaunchKernelGGL(text_embed_kernel<resid_t>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (resid_t*)x, C, T, d, vocab);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
@@ -150,8 +165,20 @@ int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb
 // Patch gather (the conv1 of models/clip_encoders.py:131 as a GEMM operand):
 //   out[(b*G + py)*G + px][c*p*p + kh*p + kw] = img[b][c][py*p + kh][px*p + kw], zero-padded to Kpad.
 // One thread writes 8 consecutive k (16 bytes).
-template <typename T>
-__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ img, half_t* __restrict__ out, int B, int R, int p, int Kpad) {
+template <typename OT>
+__device__ __forceinline__ void store8(OT* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<half_t>(half_t* p, const float (&v)[8]) {
+    *(half8*)p = (half8){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3], (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+}
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    ((f32x4*)p)[0] = (f32x4){v[0], v[1], v[2], v[3]};
+    ((f32x4*)p)[1] = (f32x4){v[4], v[5], v[6], v[7]};
+}
+
+template <typename T, typename OT>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ img, OT* __restrict__ out, int B, int R, int p, int Kpad) {
     const int G = R / p;
     const int K = 3 * p * p;
     const int chunks = Kpad >> 3;
@@ -163,12 +190,12 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ img, 
         const int py = (int)((prow / G) % G);
         const int b = (int)(prow / ((size_t)G * G));
         const int k0 = chunk * 8;
-        half8 h;
+        float h[8];
         if ((p & 7) == 0 && k0 + 8 <= K) {
             const int c = k0 / (p * p), rem = k0 - c * p * p, kh = rem / p, kw = rem - kh * p;
             const T* src = img + (((size_t)b * 3 + c) * R + (py * p + kh)) * R + px * p + kw;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)src[j];
+            for (int j = 0; j < 8; ++j) h[j] = (float)src[j];
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -178,36 +205,42 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ img, 
                     const int c = k / (p * p), rem = k - c * p * p, kh = rem / p, kw = rem - kh * p;
                     v = (float)img[(((size_t)b * 3 + c) * R + (py * p + kh)) * R + px * p + kw];
                 }
-                h[j] = (half_t)v;
+                h[j] = v;
             }
         }
-        *(half8*)(out + prow * Kpad + k0) = h;
+        store8<OT>(out + prow * Kpad + k0, h);
     }
 }
 
-int launch_im2col(const void* images, int images_f16, half_t* out, int B, int R, int patch, int Kpad, hipStream_t s) {
+int launch_im2col(const void* images, int images_f16, void* out, int out_f32, int B, int R, int patch, int Kpad, hipStream_t s) {
     GRIP_REQUIRE(R % patch == 0 && Kpad % 8 == 0, "im2col: bad geometry R=%d patch=%d", R, patch);
     const int G = R / patch;
     const size_t total = (size_t)B * G * G * (Kpad / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    if (images_f16)
-        hipLaunchKernelGGL(im2col_kernel<half_t>, dim3(blocks), dim3(256), 0, s, (const half_t*)images, out, B, R, patch, Kpad);
+    if (out_f32) {
+        if (images_f16)
+            hipLaunchKernelGGL((im2col_kernel<half_t, float>), dim3(blocks), dim3(256), 0, s, (const half_t*)images, (float*)out, B, R, patch, Kpad);
+        else
+            hipLaunchKernelGGL((im2col_kernel<float, float>), dim3(blocks), dim3(256), 0, s, (const float*)images, (float*)out, B, R, patch, Kpad);
+    } else if (images_f16)
+        hipLaunchKernelGGL((im2col_kernel<half_t, half_t>), dim3(blocks), dim3(256), 0, s, (const half_t*)images, (half_t*)out, B, R, patch, Kpad);
     else
-        hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)images, out, B, R, patch, Kpad);
+        hipLaunchKernelGGL((im2col_kernel<float, half_t>), dim3(blocks), dim3(256), 0, s, (const float*)images, (half_t*)out, B, R, patch, Kpad);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // out[c][r] = in[r][c] (f16), 64x64 tiles through LDS; used once per weight in grip_tower_finalize.
-__global__ __launch_bounds__(256) void transpose_f16_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int rows, int cols, int ld_in) {
-    __shared__ half_t tile[64][66];
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, int cols, int ld_in) {
+    __shared__ T tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (half_t)0.f;
+        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (T)0.f;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
@@ -216,8 +249,11 @@ __global__ __launch_bounds__(256) void transpose_f16_kernel(const half_t* __rest
     }
 }
 
-int launch_transpose_f16(const half_t* in, half_t* out, int rows, int cols, int ld_in, hipStream_t s) {
-    hipLaunchKernelGGL(transpose_f16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, in, out, rows, cols, ld_in);
+int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int ld_in, hipStream_t s) {
+    if (f32)
+        hipLaunchKernelGGL(transpose_kernel<float>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, (const float*)in, (float*)out, rows, cols, ld_in);
+    else
+        hipLaunchKernelGGL(transpose_kernel<half_t>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, (const half_t*)in, (half_t*)out, rows, cols, ld_in);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

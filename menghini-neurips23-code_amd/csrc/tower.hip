@@ -10,6 +10,7 @@
 // tile in the workspace; padding rows are never stored to and never read back.
 #include <stdarg.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -140,6 +141,8 @@ extern "C" int grip_layout_size(const grip_dims* dims, int64_t* n_f16, int64_t* 
 }
 
 // ---------------------------------------------------------------------------------------------- handle
+// Activation buffers are declared half_t* but hold f32 elements in exact mode (element size `es` below); the forward passes
+// them on as untyped pointers + the f32 flag, and the backward (f16 towers only) uses them as declared.
 struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, train) problem
     int batch = 0, P = 0, train = 0, S = 0, M = 0;
     int64_t Mp = 0;
@@ -170,20 +173,33 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
 struct grip_tower {
     grip_dims D;
     Layout L;
-    half_t* w16;
+    half_t* w16;      // GEMM-operand blob: f16, or f32 when f32 != 0 (exact mode) -- always addressed through wop()
     float* w32;
+    int f32 = 0;      // dims.precision: 0 = f16 operands / f16 residual stream, 1 = f32 everywhere (comparison mode, inference only)
+    uint64_t generation = 0;   // counts train-mode forwards (see `pending`)
+    const void* wop(int64_t elem_off) const { return (const char*)w16 + elem_off * (f32 ? 4 : 2); }
+    void* wop(int64_t elem_off) { return (char*)w16 + elem_off * (f32 ? 4 : 2); }
     bool finalized = false;
-    // state of the last train-mode forward (for backward)
-    Workspace last;
-    void* last_ws = nullptr;
-    const int32_t* last_eot = nullptr;
-    int last_prefix_classes = 0;
+    // State of the train-mode forwards whose activations are still waiting for their backward, keyed by workspace: several
+    // forwards may be outstanding at once (model(aug_1) and model(aug_2) before one loss.backward()), each on its own
+    // workspace.  A second train-mode forward on the SAME workspace overwrites the first one's activations; its generation
+    // number replaces the first one's, so a backward that presents the old generation fails with GRIP_ERR_STATE instead
+    // of returning gradients of the wrong forward.
+    struct TrainState {
+        Workspace w;
+        const int32_t* eot = nullptr;
+        int prefix_classes = 0;
+        uint64_t generation = 0;
+    };
+    std::map<void*, TrainState> pending;
 };
 
 static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w, int seq_len = 0) {
     const grip_dims& D = t->D;
     GRIP_REQUIRE(batch > 0 && P >= 0 && P <= D.max_prefix, "batch must be positive and 0 <= n_prefix <= max_prefix (batch=%d n_prefix=%d max=%d)", batch, P, D.max_prefix);
     const int64_t d = D.width;
+    const size_t es = t->f32 ? 4 : 2;      // activation / operand element size
+    GRIP_REQUIRE(!(t->f32 && train), "exact (f32) towers are inference-only: no train-mode workspace");
     w.batch = batch; w.P = P; w.train = train;
     GRIP_REQUIRE(seq_len >= 0 && seq_len <= D.seq0 && (D.kind == 1 || seq_len == 0), "seq_len %d out of range", seq_len);
     w.S = D.kind == 0 ? D.seq0 + P : (seq_len ? seq_len : D.seq0);
@@ -194,15 +210,15 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     const int64_t Bp = round_up64(batch, 256);
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return (void*)p; };
-    if (!train) w.x = (resid_t*)take(w.Mp * d * sizeof(resid_t));
-    w.xn = (half_t*)take(w.Mp * d * 2);
-    if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * 2); w.att = (half_t*)take(w.Mp * d * 2); }
-    w.h = (half_t*)take(w.Mp * 4 * d * 2);
-    w.cls16 = (half_t*)take(Bp * d * 2);
+    if (!train) w.x = (resid_t*)take(w.Mp * d * es);
+    w.xn = (half_t*)take(w.Mp * d * es);
+    if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * es); w.att = (half_t*)take(w.Mp * d * es); }
+    w.h = (half_t*)take(w.Mp * 4 * d * es);
+    w.cls16 = (half_t*)take(Bp * d * es);
     if (D.kind == 0) {
         const int64_t G2 = D.seq0 - 1;
         const int64_t prow = round_up64(batch * G2, 256);
-        w.patches = prow * t->L.kpad <= w.Mp * 4 * d ? w.h : (half_t*)take(prow * t->L.kpad * 2);   // alias of h when it fits
+        w.patches = prow * t->L.kpad <= w.Mp * 4 * d ? w.h : (half_t*)take(prow * t->L.kpad * es);   // alias of h when it fits
         w.patch_out = (float*)take(batch * G2 * d * 4);
     }
     if (train) {
@@ -235,6 +251,8 @@ extern "C" int grip_tower_create(const grip_dims* dims, void* f16_blob, void* f3
     try {
         grip_tower* t = new grip_tower();
         t->D = *dims;
+        if (dims->precision != 0 && dims->precision != 1) { delete t; GRIP_REQUIRE(false, "dims.precision must be 0 (f16) or 1 (f32 exact)"); }
+        t->f32 = dims->precision;
         int rc = build_layout(*dims, t->L);
         if (rc) { delete t; return rc; }
         t->w16 = (half_t*)f16_blob;
@@ -254,13 +272,15 @@ extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int d = t->D.width;
     int rc;
-    for (const LayerW& w : t->L.layer) {
-        if ((rc = launch_transpose_f16(t->w16 + w.in_w, t->w16 + w.in_wT, 3 * d, d, d, s))) return rc;
-        if ((rc = launch_transpose_f16(t->w16 + w.out_w, t->w16 + w.out_wT, d, d, d, s))) return rc;
-        if ((rc = launch_transpose_f16(t->w16 + w.fc_w, t->w16 + w.fc_wT, 4 * d, d, d, s))) return rc;
-        if ((rc = launch_transpose_f16(t->w16 + w.proj_w, t->w16 + w.proj_wT, d, 4 * d, 4 * d, s))) return rc;
-    }
-    if ((rc = launch_transpose_f16(t->w16 + t->L.proj, t->w16 + t->L.projT, d, t->D.embed_dim, t->D.embed_dim, s))) return rc;
+    const int f = t->f32;
+    if (!f)       // the per-layer transposes feed the dgrad GEMMs only: exact towers have no backward
+        for (const LayerW& w : t->L.layer) {
+            if ((rc = launch_transpose(t->wop(w.in_w), t->wop(w.in_wT), f, 3 * d, d, d, s))) return rc;
+            if ((rc = launch_transpose(t->wop(w.out_w), t->wop(w.out_wT), f, d, d, d, s))) return rc;
+            if ((rc = launch_transpose(t->wop(w.fc_w), t->wop(w.fc_wT), f, 4 * d, d, d, s))) return rc;
+            if ((rc = launch_transpose(t->wop(w.proj_w), t->wop(w.proj_wT), f, d, 4 * d, 4 * d, s))) return rc;
+        }
+    if ((rc = launch_transpose(t->wop(t->L.proj), t->wop(t->L.projT), f, d, t->D.embed_dim, t->D.embed_dim, s))) return rc;
     t->finalized = true;
     return GRIP_OK;
 }
@@ -280,8 +300,7 @@ extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipStream_t s, resid_t** x_final) {
-    const int d = t->D.width, H = t->D.heads;
-    const half_t* W = t->w16;
+    const int d = t->D.width, H = t->D.heads, f = t->f32;
     const float* F = t->w32;
     resid_t* x = x0;
     for (int l = 0; l < t->D.layers; ++l) {
@@ -290,21 +309,22 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipS
         half_t* att = w.train ? w.att_l[(size_t)l] : w.att;
         resid_t* x_mid = w.train ? w.x_mid[(size_t)l] : x;
         resid_t* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
-        RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, w.M, d, s));
+        RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, f, w.M, d, s));
         GemmArgs a{};
-        a.A = w.xn; a.W = W + lw.in_w; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
+        a.f32 = f; a.A = w.xn; a.W = t->wop(lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
         RUN(launch_gemm(EPI_BIAS_F16, a, s));
-        RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
+        if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s));
+        else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
         a = GemmArgs{};
-        a.A = att; a.W = W + lw.out_w; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
+        a.f32 = f; a.A = att; a.W = t->wop(lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
-        RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, w.M, d, s));
+        RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, f, w.M, d, s));
         a = GemmArgs{};
-        a.A = w.xn; a.W = W + lw.fc_w; a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.h; a.ldc = 4 * d;
+        a.f32 = f; a.A = w.xn; a.W = t->wop(lw.fc_w); a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.h; a.ldc = 4 * d;
         a.out2 = w.train ? w.hpre_l[(size_t)l] : nullptr;
         RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
         a = GemmArgs{};
-        a.A = w.h; a.W = W + lw.proj_w; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
+        a.f32 = f; a.A = w.h; a.W = t->wop(lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         x = x_out;
     }
@@ -321,8 +341,21 @@ static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t
     return GRIP_OK;
 }
 
+// Book-keeping of a finished forward: a train-mode one registers its state under the workspace (replacing whatever
+// forward used that workspace before) and hands out a fresh generation number; an inference one invalidates it.
+static void note_forward(grip_tower* t, void* workspace, int train, const Workspace& w, const int32_t* eot, int prefix_classes, uint64_t* generation) {
+    if (train) {
+        grip_tower::TrainState& st = t->pending[workspace];
+        st.w = w; st.eot = eot; st.prefix_classes = prefix_classes; st.generation = ++t->generation;
+        if (generation) *generation = st.generation;
+    } else {
+        t->pending.erase(workspace);
+        if (generation) *generation = 0;
+    }
+}
+
 extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f16, const float* prefix, int n_prefix,
-                                int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, void* stream) {
+                                int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 0, "vit_forward: not a vision tower");
         GRIP_REQUIRE(images && out_emb && (n_prefix == 0 || prefix), "vit_forward: null pointer");
@@ -330,29 +363,28 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         RUN(check_ws(t, batch, n_prefix, train, workspace, workspace_bytes, w));
         hipStream_t s = (hipStream_t)stream;
         const grip_dims& D = t->D;
-        const int d = D.width, G2 = D.seq0 - 1;
-        const half_t* W = t->w16;
+        const int d = D.width, G2 = D.seq0 - 1, f = t->f32;
         const float* F = t->w32;
-        RUN(launch_im2col(images, images_f16, w.patches, batch, D.resolution, D.patch, t->L.kpad, s));
+        RUN(launch_im2col(images, images_f16, w.patches, f, batch, D.resolution, D.patch, t->L.kpad, s));
         GemmArgs a{};
-        a.A = w.patches; a.W = W + t->L.conv_w; a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
+        a.f32 = f; a.A = w.patches; a.W = t->wop(t->L.conv_w); a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, batch, G2, d, s));
+        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, batch, G2, d, s));
         resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/0, s, &xf));
-        RUN(launch_gather_ln_f16(xf, nullptr, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, batch, d, s));
+        RUN(launch_gather_ln_f16(xf, nullptr, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, batch, d, s));
         a = GemmArgs{};
-        a.A = w.cls16; a.W = W + t->L.projT; a.M = batch; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
+        a.f32 = f; a.A = w.cls16; a.W = t->wop(t->L.projT); a.M = batch; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
         RUN(launch_gemm(EPI_F32, a, s));
-        if (train) { t->last = w; t->last_ws = workspace; } else if (t->last_ws == workspace) { t->last_ws = nullptr; }
+        note_forward(t, workspace, train, w, nullptr, 0, generation);
         return GRIP_OK;
     } catch (...) { grip_set_error("vit_forward: exception"); return GRIP_ERR_ARG; }
 }
 
 extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
                                  int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
-                                 void* workspace, size_t workspace_bytes, int train, void* stream) {
+                                 void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 1, "text_forward: not a text tower");
         GRIP_REQUIRE(token_ids && eot_index && out_emb && (n_prefix == 0 || prefix), "text_forward: null pointer");
@@ -361,19 +393,17 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         RUN(check_ws(t, n_class, n_prefix, train, workspace, workspace_bytes, w, seq_len));
         hipStream_t s = (hipStream_t)stream;
         const grip_dims& D = t->D;
-        const int d = D.width;
-        const half_t* W = t->w16;
+        const int d = D.width, f = t->f32;
         const float* F = t->w32;
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, n_class, w.S, d, D.vocab, s));
+        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, n_class, w.S, d, D.vocab, s));
         resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/1, s, &xf));
-        RUN(launch_gather_ln_f16(xf, eot_index, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, n_class, d, s));
+        RUN(launch_gather_ln_f16(xf, eot_index, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, n_class, d, s));
         GemmArgs a{};
-        a.A = w.cls16; a.W = W + t->L.projT; a.M = n_class; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
+        a.f32 = f; a.A = w.cls16; a.W = t->wop(t->L.projT); a.M = n_class; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
         RUN(launch_gemm(EPI_F32, a, s));
-        if (train) { t->last = w; t->last_ws = workspace; t->last_eot = eot_index; t->last_prefix_classes = prefix_classes; }
-        else if (t->last_ws == workspace) { t->last_ws = nullptr; }
+        note_forward(t, workspace, train, w, eot_index, prefix_classes, generation);
         return GRIP_OK;
     } catch (...) { grip_set_error("text_forward: exception"); return GRIP_ERR_ARG; }
 }
@@ -385,9 +415,13 @@ extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int
                                const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream) {
     GemmArgs a{};
     a.variant = variant;
-    a.A = (const half_t*)A; a.W = (const half_t*)W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = (const resid_t*)resid;
-    a.aux = (const half_t*)aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid;
+    a.aux = aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
+    if (variant == 7) { a.f32 = 1; a.variant = 0; }   // f32 operands: the exact-mode kernel (gemm_f32.hip)
     return launch_gemm(epi, a, (hipStream_t)stream);
+}
+extern "C" int grip_debug_attention_exact(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
+    return launch_attention_fwd_f32((const float*)qkv, (float*)out, B, S, H, causal, (hipStream_t)stream);
 }
 extern "C" int grip_debug_attention(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
     return launch_attention_fwd((const half_t*)qkv, (half_t*)out, B, S, H, causal, (hipStream_t)stream);
@@ -439,22 +473,35 @@ static int backward_head_of_tower(grip_tower* t, Workspace& w, const float* grad
     return GRIP_OK;
 }
 
-static int check_bwd(grip_tower* t, void* workspace, size_t workspace_bytes) {
+// Finds the pending train-mode forward of `workspace`.  generation != 0 must equal the number that forward handed out: a later
+// train-mode forward on the same workspace has overwritten the activations, and the gradients would silently be those of
+// the wrong forward.  The entry is consumed: one backward per forward.
+static int check_bwd(grip_tower* t, void* workspace, size_t workspace_bytes, uint64_t generation, grip_tower::TrainState& st) {
     GRIP_REQUIRE(t && workspace, "backward: null pointer");
-    if (t->last_ws != workspace || !t->last.train) {
+    auto it = t->pending.find(workspace);
+    if (it == t->pending.end() || !it->second.w.train) {
         grip_set_error("backward without a matching train-mode forward on this workspace");
         return GRIP_ERR_STATE;
     }
-    if (t->last.bytes > workspace_bytes) { grip_set_error("backward: workspace too small"); return GRIP_ERR_WORKSPACE; }
+    if (generation != 0 && it->second.generation != generation) {
+        grip_set_error("backward: the activations of forward #%llu were overwritten by forward #%llu on the same workspace "
+                       "(two train-mode forwards before a backward need two workspaces)",
+                       (unsigned long long)generation, (unsigned long long)it->second.generation);
+        return GRIP_ERR_STATE;
+    }
+    if (it->second.w.bytes > workspace_bytes) { grip_set_error("backward: workspace too small"); return GRIP_ERR_WORKSPACE; }
+    st = it->second;
+    t->pending.erase(it);
     return GRIP_OK;
 }
 
 extern "C" int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* prefix, float* grad_prefix,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
+                                        void* workspace, size_t workspace_bytes, uint64_t generation, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 0 && grad_emb && prefix && grad_prefix, "vit_backward_prefix: bad arguments");
-        RUN(check_bwd(t, workspace, workspace_bytes));
-        Workspace& w = t->last;
+        grip_tower::TrainState st;
+        RUN(check_bwd(t, workspace, workspace_bytes, generation, st));
+        Workspace& w = st.w;
         GRIP_REQUIRE(w.P > 0, "vit_backward_prefix: forward had no prompt tokens");
         hipStream_t s = (hipStream_t)stream;
         RUN(backward_head_of_tower(t, w, grad_emb, nullptr, s));
@@ -465,16 +512,17 @@ extern "C" int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, co
 }
 
 extern "C" int grip_text_backward_prefix(grip_tower* t, const float* grad_emb, float* grad_prefix,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+                                         void* workspace, size_t workspace_bytes, uint64_t generation, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 1 && grad_emb && grad_prefix, "text_backward_prefix: bad arguments");
-        RUN(check_bwd(t, workspace, workspace_bytes));
-        Workspace& w = t->last;
+        grip_tower::TrainState st;
+        RUN(check_bwd(t, workspace, workspace_bytes, generation, st));
+        Workspace& w = st.w;
         GRIP_REQUIRE(w.P > 0, "text_backward_prefix: forward had no prompt tokens");
         hipStream_t s = (hipStream_t)stream;
-        RUN(backward_head_of_tower(t, w, grad_emb, t->last_eot, s));
+        RUN(backward_head_of_tower(t, w, grad_emb, st.eot, s));
         RUN(run_blocks_backward(t, w, 1, s));
-        RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, w.batch, w.S, w.P, t->last_prefix_classes, t->D.width, s));
+        RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, w.batch, w.S, w.P, st.prefix_classes, t->D.width, s));
         return GRIP_OK;
     } catch (...) { grip_set_error("text_backward_prefix: exception"); return GRIP_ERR_ARG; }
 }

@@ -4,7 +4,8 @@ torch is used for device memory, streams and autograd bookkeeping only; every FL
 encoders, the head and the losses runs in libgrip_amd.so (csrc/*.hip).
 """
 import ctypes
-from ctypes import byref, c_int64, c_size_t, c_void_p
+import weakref
+from ctypes import byref, c_int64, c_size_t, c_uint64, c_void_p
 
 import torch
 
@@ -33,14 +34,16 @@ class Tower:
     """One frozen CLIP tower (vision or text) living in two HBM blobs behind a native handle."""
 
     def __init__(self, kind, width, layers, heads, embed_dim, seq0, patch=0, resolution=0, vocab=0,
-                 max_prefix=64, device="cuda"):
+                 max_prefix=64, device="cuda", exact=False):
         self.device = require_gpu(device)
         self.lib = native.lib()
-        self.dims = native.Dims(kind, width, layers, heads, embed_dim, seq0, patch, resolution, vocab, max_prefix)
+        self.exact = bool(exact)     # f32 weights / activations / attention (comparison mode, inference only)
+        self.dims = native.Dims(kind, width, layers, heads, embed_dim, seq0, patch, resolution, vocab, max_prefix, int(self.exact))
         self.kind, self.width, self.embed_dim, self.seq0 = kind, width, embed_dim, seq0
         n16, n32 = c_int64(), c_int64()
         native.check(self.lib.grip_layout_size(byref(self.dims), byref(n16), byref(n32)))
-        self.blob16 = torch.zeros(n16.value, dtype=torch.float16, device=self.device)
+        # the GEMM-operand blob: f16, or f32 elements in exact mode (same element offsets)
+        self.blob16 = torch.zeros(n16.value, dtype=torch.float32 if self.exact else torch.float16, device=self.device)
         self.blob32 = torch.zeros(n32.value, dtype=torch.float32, device=self.device)
         self.slots = {}
         s, i = native.Slot(), 0
@@ -51,6 +54,7 @@ class Tower:
         native.check(self.lib.grip_tower_create(byref(self.dims), _ptr(self.blob16), _ptr(self.blob32), byref(h)))
         self.handle = h
         self._ws = {}
+        self._owners = {}
         self._finalized = False
 
     def __del__(self):
@@ -81,19 +85,44 @@ class Tower:
 
     # ---- workspaces
     def workspace(self, batch, n_prefix, train, seq_len=0):
+        """Inference workspaces are interchangeable (the largest is kept).  Train-mode workspaces hold the activations a
+        backward still needs: each shape keeps a small pool, and a workspace whose forward is still waiting for its
+        backward (its autograd ctx is alive and has not run) is never handed out again -- model(aug_1) and model(aug_2)
+        before one loss.backward() get two workspaces instead of overwriting each other."""
         key = (batch, n_prefix, bool(train), seq_len)
+        if train:
+            pool = self._ws.setdefault(key, [])
+            for ws in pool:
+                if not self._busy(ws):
+                    return ws
+            nbytes = c_size_t()
+            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, seq_len, 1, byref(nbytes)))
+            ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+            pool.append(ws)
+            return ws
         ws = self._ws.get(key)
         if ws is None:
             nbytes = c_size_t()
-            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, seq_len, int(train), byref(nbytes)))
-            if not train:   # inference workspaces are interchangeable: keep only the largest
-                for k in [k for k in self._ws if not k[2]]:
-                    if self._ws[k].numel() >= nbytes.value:
-                        return self._ws[k]
-                    del self._ws[k]
+            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, seq_len, 0, byref(nbytes)))
+            for k in [k for k in self._ws if not k[2]]:
+                if self._ws[k].numel() >= nbytes.value:
+                    return self._ws[k]
+                del self._ws[k]
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
         return ws
+
+    def _busy(self, ws):
+        owner = self._owners.get(ws.data_ptr())
+        return owner is not None and owner() is not None
+
+    def hold(self, ws, ctx):
+        """Mark a train-mode workspace as owned by the autograd ctx of its forward until that ctx's backward ran
+        (release) or the graph was dropped (the weak reference dies)."""
+        self._owners[ws.data_ptr()] = weakref.ref(ctx)
+
+    def release(self, ws):
+        self._owners.pop(ws.data_ptr(), None)
 
     @staticmethod
     def _aligned(ws):
@@ -115,8 +144,10 @@ class Tower:
         out = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, P, train)
         p, n = self._aligned(ws)
+        gen = c_uint64(0)
         native.check(self.lib.grip_vit_forward(self.handle, _ptr(images), int(images.dtype == torch.float16), _ptr(prefix), P, B,
-                                               _ptr(out), p, n, int(train), _stream()))
+                                               _ptr(out), p, n, int(train), byref(gen), _stream()))
+        ws.generation = gen.value
         return out, ws
 
     @torch.no_grad()
@@ -154,19 +185,19 @@ class Tower:
                     x.record_stream(self._enc_streams[k])
                 o = out[s - lo: e - lo]
                 p, n = self._aligned(self._enc_ws[k])
-                native.check(self.lib.grip_vit_forward(self.handle, _ptr(x), int(x.dtype == torch.float16), _ptr(prefix), P, e - s, _ptr(o), p, n, 0,
+                native.check(self.lib.grip_vit_forward(self.handle, _ptr(x), int(x.dtype == torch.float16), _ptr(prefix), P, e - s, _ptr(o), p, n, 0, None,
                                                        c_void_p((self._enc_streams[k] if streams == 2 else main).cuda_stream)))
         for st in self._enc_streams:
             main.wait_stream(st)
         return out
 
-    def vit_backward(self, grad_emb, prefix, ws):
+    def vit_backward(self, grad_emb, prefix, ws, generation=0):
         P = prefix.shape[-2]
         prefix = prefix.reshape(P, self.width).contiguous().float()
         grad_emb = grad_emb.contiguous().float()
         g = torch.empty(P, self.width, dtype=torch.float32, device=self.device)
         p, n = self._aligned(ws)
-        native.check(self.lib.grip_vit_backward_prefix(self.handle, _ptr(grad_emb), _ptr(prefix), _ptr(g), p, n, _stream()))
+        native.check(self.lib.grip_vit_backward_prefix(self.handle, _ptr(grad_emb), _ptr(prefix), _ptr(g), p, n, generation, _stream()))
         return g
 
     # Encode only the positions up to the longest prompt's EOT: the text transformer is causal and only the EOT row is
@@ -189,26 +220,28 @@ class Tower:
         out = torch.empty(C, self.embed_dim, dtype=torch.float32, device=self.device)
         ws = self.workspace(C, P, train, seq_len)
         p, n = self._aligned(ws)
+        gen = c_uint64(0)
         native.check(self.lib.grip_text_forward(self.handle, _ptr(ids), _ptr(eot), _ptr(prefix), P, pc, C, seq_len, _ptr(out), p, n,
-                                                int(train), _stream()))
+                                                int(train), byref(gen), _stream()))
+        ws.generation = gen.value
         return out, ws, (ids, eot, seq_len)
 
-    def text_backward(self, grad_emb, prefix_shape, ws):
+    def text_backward(self, grad_emb, prefix_shape, ws, generation=0):
         grad_emb = grad_emb.contiguous().float()
         g = torch.empty(prefix_shape, dtype=torch.float32, device=self.device)
         p, n = self._aligned(ws)
-        native.check(self.lib.grip_text_backward_prefix(self.handle, _ptr(grad_emb), _ptr(g), p, n, _stream()))
+        native.check(self.lib.grip_text_backward_prefix(self.handle, _ptr(grad_emb), _ptr(g), p, n, generation, _stream()))
         return g
 
 
-def vision_tower(d: ClipDims, device="cuda", max_prefix=64):
+def vision_tower(d: ClipDims, device="cuda", max_prefix=64, exact=False):
     return Tower(0, d.vision_width, d.vision_layers, d.vision_heads, d.embed_dim, d.vision_seq, d.vision_patch_size,
-                 d.image_resolution, 0, max_prefix, device)
+                 d.image_resolution, 0, max_prefix, device, exact)
 
 
-def text_tower(d: ClipDims, device="cuda", max_prefix=64):
+def text_tower(d: ClipDims, device="cuda", max_prefix=64, exact=False):
     return Tower(1, d.transformer_width, d.transformer_layers, d.transformer_heads, d.embed_dim, d.context_length, 0, 0,
-                 d.vocab_size, max_prefix, device)
+                 d.vocab_size, max_prefix, device, exact)
 
 
 # ------------------------------------------------------------------------------------------ autograd
@@ -218,8 +251,12 @@ class VitPrefixFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tower, images, prefix):
         need = ctx.needs_input_grad[2]   # grad mode is off inside Function.forward
+        if need and tower.exact:
+            raise native.GripError("exact (f32) towers are inference-only: prompt gradients need a default-precision tower")
         out, ws = tower.vit_forward(images, prefix.detach(), train=need)
-        ctx.tower, ctx.ws = tower, ws
+        ctx.tower, ctx.ws, ctx.generation = tower, ws, ws.generation
+        if need:
+            tower.hold(ws, ctx)
         ctx.save_for_backward(prefix.detach())
         ctx.pshape, ctx.pdtype = prefix.shape, prefix.dtype
         return out
@@ -227,7 +264,8 @@ class VitPrefixFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (prefix,) = ctx.saved_tensors
-        g = ctx.tower.vit_backward(grad_out, prefix, ctx.ws)
+        g = ctx.tower.vit_backward(grad_out, prefix, ctx.ws, ctx.generation)
+        ctx.tower.release(ctx.ws)
         return None, None, g.reshape(ctx.pshape).to(ctx.pdtype)
 
 
@@ -237,17 +275,22 @@ class TextPrefixFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tower, token_ids, prefix):
         need = ctx.needs_input_grad[2]
+        if need and tower.exact:
+            raise native.GripError("exact (f32) towers are inference-only: prompt gradients need a default-precision tower")
         cached = getattr(token_ids, "_grip_seq_len", None)
         out, ws, keep = tower.text_forward(token_ids, prefix.detach(), train=need, seq_len=cached)
         token_ids._grip_seq_len = keep[2]
-        ctx.tower, ctx.ws = tower, ws
+        ctx.tower, ctx.ws, ctx.generation = tower, ws, ws.generation
+        if need:
+            tower.hold(ws, ctx)
         ctx.keep = keep   # the native handle remembers the EOT-index pointer until backward
         ctx.pshape, ctx.pdtype = prefix.shape, prefix.dtype
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        g = ctx.tower.text_backward(grad_out, tuple(ctx.pshape), ctx.ws)
+        g = ctx.tower.text_backward(grad_out, tuple(ctx.pshape), ctx.ws, ctx.generation)
+        ctx.tower.release(ctx.ws)
         return None, None, g.to(ctx.pdtype)
 
 

@@ -110,7 +110,13 @@ class TrainingStrategy:
         m = self.unwrap_model()
         if self.modality in ("text", "image"):
             return [m.prefix.detach().cpu().numpy()]
-        return copy.deepcopy({k: v.detach().cpu() for k, v in m.state_dict().items()})
+        # multimodal_prompt.py:149-158 of the reference: the eight trainable pieces, positionally -- NOT the whole UPTModel
+        # state_dict, which would drag ~1 GB of frozen CLIP weights (registered sub-modules) to the host every epoch.
+        sd = lambda mod: copy.deepcopy({k: v.detach().cpu() for k, v in mod.state_dict().items()})   # noqa: E731
+        return [sd(m.transformer), sd(m.proj_coop_pre), sd(m.proj_coop_post), sd(m.proj_vpt_pre), sd(m.proj_vpt_post),
+                m.coop_embeddings.detach().cpu().numpy(),
+                None if m.vpt_embeddings_deep is None else m.vpt_embeddings_deep.detach().cpu().numpy(),
+                m.vpt_embeddings.detach().cpu().numpy()]
 
     # ------------------------------------------------------------------ features
     def text_prompts(self, classes):
@@ -182,10 +188,11 @@ class TrainingStrategy:
             seen_imgs = list(train_data.filepaths)
             seen_labs = [l if train_data.label_id else self.label_to_idx[l] for l in train_data.labels]
             n_u, n_s = max(len(unseen_imgs), 1), max(len(seen_imgs), 1)
-            if self.paradigm == "ssl":
-                self.balance_param = math.sqrt(n_u / n_s) if self.modality == "multi" else n_u / n_s
-            else:
-                self.balance_param = n_s / n_u
+            # ssl: |unseen| / |seen| (semi_supervised_learning/textual_fpl.py:115, visual_fpl.py:110), trzsl: |seen| / |unseen|
+            # (transductive_zsl/textual_fpl.py:109, visual_fpl.py:105); the multimodal strategies take the square root in both
+            # paradigms (semi_supervised_learning/multimodal_fpl.py:107, transductive_zsl/multimodal_fpl.py:104)
+            ratio = n_u / n_s if self.paradigm == "ssl" else n_s / n_u
+            self.balance_param = math.sqrt(ratio) if self.modality == "multi" else ratio
             train_data.filepaths, train_data.labels = unseen_imgs + seen_imgs, unseen_labs + seen_labs
         train_data.label_id = True
         return train_data
@@ -280,17 +287,33 @@ class TrainingStrategy:
 
     # ------------------------------------------------------------------ pseudolabels from the trained model
     @torch.no_grad()
+    def trained_features(self, images, classes, chunk=440):
+        """(image features [N, E] of the whole ordered pool, text features [C, E]) of the CURRENT model for the pseudolabel pass.
+        The image side goes through pseudolabels.encode_pool: chunked, sharded contiguously over the ranks of one node, one
+        all-gather of the embeddings -- with the trained visual prompt where the modality has one.  The text
+        side is computed once per call on every rank (C x 6 GF, cheaper than a broadcast); the UPT mixer runs once.  The
+        reference does all of this per image at batch 1 (textual_fpl.py:203-205 + :225; visual_fpl.py:250 + :264;
+        multimodal_fpl.py:223 runs BOTH towers and the mixer for every image)."""
+        tower = self.clip_model.visual.tower
+        if self.modality == "text":
+            self.model.classes = classes
+            return pl.encode_pool(tower, images, chunk=chunk), self.model(classes)
+        if self.modality == "image":
+            return pl.encode_pool(tower, images, chunk=chunk, prefix=self.model.prefix.detach()), self.fixed_text_features(classes)
+        self.model.classes = classes
+        coop_embs, vpt_embs = self.model.mix()
+        txt = self.model.text_encoder(coop_embs, classes)
+        return pl.encode_pool(tower, images, chunk=chunk, prefix=vpt_embs.detach()), txt
+
+    @torch.no_grad()
     def assign_pseudo_labels(self, k, unlabeled_data):
         """The nine `assign_pseudo_labels` of the reference (e.g. transductive_zsl/multimodal_fpl.py:194-285):
-        leaderboard over the TRAINED model's logits on the unseen classes; text features are computed once per
-        call, not once per image."""
+        leaderboard over the TRAINED model's logits on the unseen classes (arg-max on the logits, :222)."""
+        from ..utils.clip_pseudolabels import _pool_images
         classes = self.unseen_classes if self.paradigm == "trzsl" else self.classes
-        feats_i, txt = [], None
-        for batch in self._loader(unlabeled_data, False):
-            image_features, text_features = self.features(batch[0].to(self.device), classes)
-            feats_i.append(image_features)
-            txt = text_features
-        fp, lab = pl.pseudolabel_from_features(torch.cat(feats_i), txt, self.scale(), list(unlabeled_data.filepaths),
+        images = _pool_images(unlabeled_data, self.transform, self.device)
+        img, txt = self.trained_features(images, classes)
+        fp, lab = pl.pseudolabel_from_features(img, txt, self.scale(), list(unlabeled_data.filepaths),
                                                [self.label_to_idx[c] for c in classes], k, argmax_on="logits")
         unlabeled_data.filepaths, unlabeled_data.labels, unlabeled_data.label_id = fp, lab, True
         return unlabeled_data

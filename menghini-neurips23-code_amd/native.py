@@ -6,11 +6,11 @@ point raises.  Nothing here imports the oracle.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrip_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GripError(RuntimeError):
@@ -19,7 +19,7 @@ class GripError(RuntimeError):
 
 class Dims(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in ("kind", "width", "layers", "heads", "embed_dim", "seq0", "patch",
-                                       "resolution", "vocab", "max_prefix")]
+                                       "resolution", "vocab", "max_prefix", "precision")]
 
 
 class Slot(ctypes.Structure):
@@ -36,10 +36,10 @@ _SIGS = {
     "grip_tower_finalize": (c_int, [c_void_p, c_void_p]),
     "grip_tower_destroy": (c_int, [c_void_p]),
     "grip_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
-    "grip_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
-    "grip_vit_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "grip_text_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
-    "grip_text_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "grip_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_uint64), c_void_p]),
+    "grip_vit_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_void_p]),
+    "grip_text_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_uint64), c_void_p]),
+    "grip_text_backward_prefix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint64, c_void_p]),
     "grip_cosine_head": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_cosine_head_backward": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_weighted_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -51,6 +51,7 @@ EXPORTS = tuple(_SIGS)   # the drop-in ABI (include/grip_amd.h)
 _DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of the ABI
     "grip_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]),
     "grip_debug_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "grip_debug_attention_exact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "grip_profile_enable": (c_int, [c_int]),
     "grip_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "grip_debug_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -259,24 +259,39 @@ def fpl_losses(out):
 
 
 def main():
+    """python oracle/gen_golden.py [small] [vitb16] [vitl14] [leaderboard]   (no argument = all four groups)"""
     os.makedirs(OUT, exist_ok=True)
     cbind.build()
+    groups = set(sys.argv[1:]) or {"small", "vitb16", "vitl14", "leaderboard"}
     classes = ["forest", "annual crop land", "river", "sea lake", "highway"]
 
-    out = {}
-    towers("tiny", 3, classes, 3, "g1", out)
-    towers("small", 2, classes[:4], 16, "g1s", out)
-    upt("tiny", 3, classes[:3], 4, "g4", out)
-    fpl_losses(out)
-    np.savez_compressed(os.path.join(OUT, "golden_small.npz"), **out)
+    if "small" in groups:
+        out = {}
+        towers("tiny", 3, classes, 3, "g1", out)
+        towers("small", 2, classes[:4], 16, "g1s", out)
+        upt("tiny", 3, classes[:3], 4, "g4", out)
+        fpl_losses(out)
+        np.savez_compressed(os.path.join(OUT, "golden_small.npz"), **out)
 
-    big = {}
-    towers("ViT-B/16", 2, classes[:3], 16, "g3", big, with_grad=False)
-    np.savez_compressed(os.path.join(OUT, "golden_vitb16.npz"), **big)
+    if "vitb16" in groups:
+        # G3: full-size ViT-B/16 + text-B spot check, incl. the prompt gradients of the step bench.py times (CoOp: [1,16,512]
+        # through the 12-layer text tower; VPT: [16,768] through the 12-layer ViT) and UPT end to end at these dimensions
+        big = {}
+        towers("ViT-B/16", 2, classes[:3], 16, "g3", big, with_grad=True)
+        upt("ViT-B/16", 2, classes[:3], 4, "g4b", big)
+        np.savez_compressed(os.path.join(OUT, "golden_vitb16.npz"), **big)
 
-    with open(os.path.join(OUT, "leaderboard.json"), "w") as f:
-        json.dump({"seed": SEED, "cases": leaderboard_cases()}, f)
-    print("wrote", os.listdir(OUT))
+    if "vitl14" in groups:
+        # BASELINE.json configs[4]: ViT-L/14@336px (d = 1024, 24 layers, 16 heads, S = 577 / 593, E = 768) + the 12-head 768-wide
+        # text tower, 2 images and 3 prompts: forward of both towers without and with 16 prompt tokens, and both prompt gradients
+        huge = {}
+        towers("ViT-L/14@336px", 2, classes[:3], 16, "g5", huge, with_grad=True)
+        np.savez_compressed(os.path.join(OUT, "golden_vitl14_336.npz"), **huge)
+
+    if "leaderboard" in groups:
+        with open(os.path.join(OUT, "leaderboard.json"), "w") as f:
+            json.dump({"seed": SEED, "cases": leaderboard_cases()}, f)
+    print("wrote", sorted(os.listdir(OUT)))
 
 
 if __name__ == "__main__":

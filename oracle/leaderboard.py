@@ -51,3 +51,57 @@ def softmax_argmax(logits):
     lg = torch.as_tensor(np.asarray(logits, dtype=np.float32))
     p = lg.softmax(dim=-1)
     return p.numpy(), torch.argmax(p, dim=1).numpy()
+
+
+def scan_margin(probs, pred_ids, k):
+    """Decision margin of the scan above on `probs`: the smallest RELATIVE gap |a - b| / max(a, b) between two fp32 values
+    whose ORDER the algorithm depends on -- (a) top-1 vs top-2 probability of an image (the arg-max, :39), (b) every strict
+    comparison `board[-1].score < score` (:75, :95), (c) neighbours in every sorted board incl. the element the truncation
+    drops (:79-82).  If another implementation's probabilities differ from `probs` by a relative error below half this
+    margin everywhere, its lists are necessarily identical.  (Softmax outputs of two fp32 implementations differ by a
+    roughly uniform RELATIVE error -- exp of a logit error -- so the margin is relative.  Order of the spill walk :83-90
+    does not matter: boards are independent and there is no `break`.  Exact ties are resolved by the path string in both
+    implementations alike and are skipped.)"""
+    probs = np.asarray(probs, dtype=np.float32)
+    n, C = probs.shape
+    gap = np.inf
+
+    def note(a, b):
+        nonlocal gap
+        a, b = float(a), float(b)
+        d = abs(a - b)
+        if d > 0.0:
+            gap = min(gap, d / max(abs(a), abs(b)))
+
+    if C > 1:
+        top2 = np.sort(probs, axis=1)[:, -2:].astype(np.float64)
+        d = top2[:, 1] - top2[:, 0]
+        if (d > 0).any():
+            gap = float(np.min((d / top2[:, 1])[d > 0]))
+    if k == K_ALL:
+        return gap
+    board = [[] for _ in range(C)]
+
+    def offer(j, score, i):
+        b = board[j]
+        if len(b) < k:
+            b.append((score, i))
+            return
+        note(b[-1][0], score)
+        if b[-1][0] < score:
+            full = sorted(b + [(score, i)], reverse=True)
+            for x, y in zip(full[:-1], full[1:]):
+                note(x[0], y[0])
+            board[j] = full[:k]
+
+    for i in range(n):
+        j0 = int(pred_ids[i])
+        b = board[j0]
+        if len(b) < k or b[-1][0] < probs[i, j0]:
+            offer(j0, probs[i, j0], i)
+        else:
+            note(b[-1][0], probs[i, j0])
+            for j in range(C):
+                if j != j0:
+                    offer(j, probs[i, j], i)
+    return gap

@@ -24,6 +24,12 @@ def golden_vitb16():
     return np.load(os.path.join(REPO, "tests", "golden", "golden_vitb16.npz"))
 
 
+@pytest.fixture(scope="session")
+def golden_vitl14():
+    import numpy as np
+    return np.load(os.path.join(REPO, "tests", "golden", "golden_vitl14_336.npz"))
+
+
 def oracle_clip():
     """The CPU oracle's `clip` stand-in (tests only)."""
     import importlib

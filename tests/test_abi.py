@@ -50,9 +50,9 @@ def test_layout_is_complete_and_non_overlapping():
     for name in ("tiny", "ViT-B/16", "ViT-L/14@336px"):
         d = config.get_dims(name)
         for kind, dims in ((0, native.Dims(0, d.vision_width, d.vision_layers, d.vision_heads, d.embed_dim, d.vision_seq,
-                                           d.vision_patch_size, d.image_resolution, 0, 16)),
+                                           d.vision_patch_size, d.image_resolution, 0, 16, 0)),
                            (1, native.Dims(1, d.transformer_width, d.transformer_layers, d.transformer_heads, d.embed_dim,
-                                           d.context_length, 0, 0, d.vocab_size, 16))):
+                                           d.context_length, 0, 0, d.vocab_size, 16, 0))):
             n16, n32 = ctypes.c_int64(), ctypes.c_int64()
             native.check(lib.grip_layout_size(ctypes.byref(dims), ctypes.byref(n16), ctypes.byref(n32)))
             slots, s, i = [], native.Slot(), 0
@@ -79,7 +79,7 @@ def test_bad_dims_are_rejected_with_a_message():
     import grip_amd  # noqa: F401
     from grip_amd import native
     lib = native.lib()
-    bad = native.Dims(0, 100, 2, 2, 128, 17, 8, 32, 0, 4)     # width not a multiple of 128
+    bad = native.Dims(0, 100, 2, 2, 128, 17, 8, 32, 0, 4, 0)     # width not a multiple of 128
     a, b = ctypes.c_int64(), ctypes.c_int64()
     assert lib.grip_layout_size(ctypes.byref(bad), ctypes.byref(a), ctypes.byref(b)) == 1
     assert b"width" in lib.grip_last_error()

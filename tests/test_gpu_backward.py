@@ -177,3 +177,72 @@ def test_vitb16_gradient_vs_oracle(models):
     pg = prefix.clone().cuda().requires_grad_(True)
     (VitPrefixFn.apply(m.visual.tower, x.cuda(), pg) * w.cuda()).sum().backward()
     assert_grad_close(pg.grad, pc.grad, "ViT-B/16 visual prompt grad")
+
+
+def _full_size_text_gradient(m, g, tag, dt, cos_tol=1e-3, rel_tol=3e-2):
+    """CoOp prompt gradient through the whole text tower against the committed reference gradient, on the path bench.py
+    times (EOT-truncated: the tower encodes only positions <= the longest EOT) AND with all 77 positions."""
+    from grip_amd.engine import TextPrefixFn
+    ctok = torch.from_numpy(g[f"{tag}.coop_tokens"]).cuda()
+    want = g[f"{tag}.text_p16_grad_prefix"]
+    tower = m.text_tower
+    for truncate in (True, False):
+        tower.truncate_text_at_eot = truncate
+        try:
+            tok = ctok.clone()          # a fresh tensor: the cached sequence length lives on the token tensor
+            tprefix = _inputs(f"{tag}.tprefix", (1, 16, dt), 0.02).cuda().requires_grad_(True)
+            out = TextPrefixFn.apply(tower, tok, tprefix)
+            assert (tok._grip_seq_len < 77) == truncate
+            (out ** 2).sum().backward()
+            assert_grad_close(tprefix.grad, want, f"{tag} textual prompt grad (truncate={truncate})", cos_tol, rel_tol)
+        finally:
+            tower.truncate_text_at_eot = True
+
+
+def test_golden_vitb16_prompt_gradients(models, golden_vitb16):
+    """G3 with gradients: the CoOp step bench.py times -- d = 512, 12 layers, P = 16, EOT-truncated --
+    and the VPT prompt gradient through the 12-layer ViT-B/16, against autograd through the reference's own wrappers."""
+    import grip_amd  # noqa: F401
+    from grip_amd.models import CustomImageEncoder, ImagePrefixModel
+    m, g = models("ViT-B/16"), golden_vitb16
+    _full_size_text_gradient(m, g, "g3", 512)
+    x = _inputs("g3.x", (2, 3, 224, 224)).cuda()
+    model = ImagePrefixModel(_inputs("g3.vprefix", (16, 768), 0.02).cuda(), CustomImageEncoder(m.visual), device="cuda")
+    (model(x) ** 2).sum().backward()
+    assert_grad_close(model.prefix.grad, g["g3.vision_p16_grad_prefix"], "g3 visual prompt grad")
+
+
+def test_golden_vitb16_upt_end_to_end(models, golden_vitb16):
+    """UPT at ViT-B/16 dimensions, Pt = Pv = 4 (BASELINE.json configs[3]): reference UPTModel output, loss and every gradient."""
+    import grip_amd  # noqa: F401
+    from grip_amd import weights
+    from grip_amd.engine import CosineHeadFn, WeightedCEFn
+    from grip_amd.models import CustomImageEncoder, CustomTextEncoder, UPTModel
+    from test_gpu_towers import assert_embeddings_close
+    g, m = golden_vitb16, models("ViT-B/16")
+    classes = ["forest", "annual crop land", "river"]
+    x = _inputs("g4b.x", (2, 3, 224, 224)).cuda()
+    upt = UPTModel(_inputs("g4b.coop", (1, 4, 512), 0.02).cuda(), _inputs("g4b.vpt", (1, 4, 768), 0.02).cuda(), None, CustomImageEncoder(m.visual),
+                   CustomTextEncoder(m, "cuda", torch.float32), classes, 128, device="cuda", dtype=torch.float32)
+    mixer = {k: torch.from_numpy(v) for k, v in weights.init_upt_mixer(512, 768, 128, SEED).items()}
+    assert not upt.load_state_dict(mixer, strict=False)[1]
+    t_out, v_out = upt(x, classes)
+    assert_embeddings_close(t_out, g["g4b.text"], "B/16 upt text")
+    assert_embeddings_close(v_out, g["g4b.vision"], "B/16 upt vision")
+    logits = CosineHeadFn.apply(v_out, t_out, m.logit_scale.exp().item())
+    loss = WeightedCEFn.apply(logits, torch.arange(2, device="cuda") % 3, torch.full((2,), 0.5, device="cuda"))
+    assert abs(loss.item() - float(g["g4b.loss"])) <= 2e-2 * max(1.0, abs(float(g["g4b.loss"])))
+    loss.backward()
+    seen = 0
+    for name, p in upt.named_parameters():
+        if f"g4b.grad.{name}" in g.files:
+            assert p.grad is not None, name
+            assert_grad_close(p.grad, g[f"g4b.grad.{name}"], name, cos_tol=5e-3, rel_tol=8e-2)
+            seen += 1
+    assert seen >= 10
+
+
+def test_golden_vitl14_336_text_gradient(models, golden_vitl14):
+    """BASELINE.json configs[4] (FGVCAircraft GRIP textual, ViT-L/14@336px): CoOp prompt gradient through the 12-head, 768-wide
+    text tower at its real dimensions."""
+    _full_size_text_gradient(models("ViT-L/14@336px"), golden_vitl14, "g5", 768)

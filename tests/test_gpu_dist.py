@@ -26,12 +26,15 @@ n = 101
 x = torch.from_numpy(rng.normal(5, rng.stream_id("dist.x"), (n, 3, 64, 64))) + 2 * torch.from_numpy(rng.normal(5, rng.stream_id("dist.mu"), (n, 3, 1, 1)))
 with torch.no_grad():
     emb = pl.encode_pool(m.visual.tower, x, chunk=16)
+    # the trained-model pass of GRIP (assign_pseudo_labels): the same sharded encode with a visual prompt
+    prefix = torch.from_numpy(rng.normal(5, rng.stream_id("dist.prefix"), (1, 4, 256), 0.0, 0.05)).cuda()
+    emb_p = pl.encode_pool(m.visual.tower, x, chunk=16, prefix=prefix)
     txt = m.encode_text(clip.tokenize(["a", "b c", "d e f", "g"]).cuda())
 lists = pl.pseudolabel_from_features(emb, txt, 100.0, [f"p{i:03d}" for i in range(n)], [0, 1, 2, 3], 5)
 g = torch.ones(3, device="cuda") * (rank + 1)
 gdist.allreduce_mean_([g])
 with open(os.environ["GRIP_OUT"] + f".{rank}", "wb") as f:
-    pickle.dump({"emb": emb.cpu(), "lists": lists, "g": g.cpu(), "ws": ws}, f)
+    pickle.dump({"emb": emb.cpu(), "emb_p": emb_p.cpu(), "lists": lists, "g": g.cpu(), "ws": ws}, f)
 gdist.barrier()
 '''
 
@@ -64,6 +67,7 @@ def test_sharded_encode_allgather_matches_single_process(tmp_path):
     r1 = pickle.load(open(str(tmp_path / "out") + ".1", "rb"))
     assert ref["ws"] == 1 and r0["ws"] == 2
     assert torch.equal(r0["emb"], ref["emb"]) and torch.equal(r1["emb"], ref["emb"])     # rows are independent of the chunking
+    assert torch.equal(r0["emb_p"], ref["emb_p"]) and torch.equal(r1["emb_p"], ref["emb_p"]) and not torch.equal(ref["emb_p"], ref["emb"])
     assert r0["lists"] == ref["lists"] and r1["lists"] == ref["lists"]
     assert torch.allclose(r0["g"], torch.full((3,), 1.5)) and torch.allclose(r1["g"], torch.full((3,), 1.5))
 

@@ -23,11 +23,11 @@ def test_workspace_too_small_and_misaligned(model):
     x = torch.randn(2, 3, 32, 32, device="cuda")
     out = torch.empty(2, 128, device="cuda")
     ws = torch.empty(4096, dtype=torch.uint8, device="cuda")
-    rc = t.lib.grip_vit_forward(t.handle, _ptr(x), 0, None, 0, 2, _ptr(out), ctypes.c_void_p(ws.data_ptr()), 4096, 0, _stream())
+    rc = t.lib.grip_vit_forward(t.handle, _ptr(x), 0, None, 0, 2, _ptr(out), ctypes.c_void_p(ws.data_ptr()), 4096, 0, None, _stream())
     assert rc == 3 and b"workspace too small" in t.lib.grip_last_error()
     big = t.workspace(2, 0, False)
     p, n = t._aligned(big)
-    rc = t.lib.grip_vit_forward(t.handle, _ptr(x), 0, None, 0, 2, _ptr(out), ctypes.c_void_p(p.value + 8), n - 8, 0, _stream())
+    rc = t.lib.grip_vit_forward(t.handle, _ptr(x), 0, None, 0, 2, _ptr(out), ctypes.c_void_p(p.value + 8), n - 8, 0, None, _stream())
     assert rc == 1 and b"aligned" in t.lib.grip_last_error()
     with pytest.raises(native.GripError):
         native.check(rc)
@@ -44,6 +44,47 @@ def test_backward_without_training_forward(model):
         t.vit_backward(torch.ones(2, 128, device="cuda"), prefix, ws)
 
 
+def test_two_forwards_before_backward(model):
+    """two grad-enabled forwards of the same shape before one backward (model(aug_1) + model(aug_2)).
+    Through the autograd Functions each forward gets its own workspace and both gradients are right; at the C ABI a
+    backward that presents the generation of an overwritten forward fails with GRIP_ERR_STATE instead of returning the
+    gradients of the wrong forward."""
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    from grip_amd.engine import VitPrefixFn
+    t = model.visual.tower
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x1 = torch.randn(2, 3, 32, 32, device="cuda", generator=g)
+    x2 = torch.randn(2, 3, 32, 32, device="cuda", generator=g)
+    p = (torch.randn(3, 128, device="cuda", generator=g) * 0.02).requires_grad_(True)
+
+    def grad_of(x):
+        p.grad = None
+        (VitPrefixFn.apply(t, x, p) ** 2).sum().backward()
+        return p.grad.clone()
+    g1, g2 = grad_of(x1), grad_of(x2)
+    p.grad = None
+    y1 = VitPrefixFn.apply(t, x1, p)
+    y2 = VitPrefixFn.apply(t, x2, p)          # same shape: must not overwrite y1's saved activations
+    ((y1 ** 2).sum() + (y2 ** 2).sum()).backward()
+    torch.testing.assert_close(p.grad, g1 + g2, rtol=1e-4, atol=1e-7)
+    # dropped graphs free their workspace again: the pool does not grow without bound
+    for _ in range(6):
+        VitPrefixFn.apply(t, x1, p)
+    assert len(t._ws[(2, 3, True, 0)]) <= 2
+    # the raw ABI: forward #a, forward #b on the SAME workspace, backward(#a) -> GRIP_ERR_STATE
+    pd = p.detach()
+    _, ws = t.vit_forward(x1, pd, train=True)
+    gen_a = ws.generation
+    _, ws_b = t.vit_forward(x2, pd, train=True)
+    assert ws_b is ws and ws.generation != gen_a
+    with pytest.raises(native.GripError, match="overwritten"):
+        t.vit_backward(torch.ones(2, 128, device="cuda"), pd, ws, gen_a)
+    t.vit_backward(torch.ones(2, 128, device="cuda"), pd, ws, ws.generation)     # the live one still works ...
+    with pytest.raises(native.GripError, match="train-mode forward"):
+        t.vit_backward(torch.ones(2, 128, device="cuda"), pd, ws, ws.generation)  # ... exactly once
+
+
 def test_bad_arguments_are_rejected(model):
     import grip_amd  # noqa: F401
     from grip_amd import native
@@ -57,7 +98,7 @@ def test_bad_arguments_are_rejected(model):
     with pytest.raises(native.GripError, match="prefix_classes"):
         tt.text_forward(ids.cuda(), torch.zeros(2, 4, 128, device="cuda"))  # prefix for 2 classes, 3 prompts
     with pytest.raises(native.GripError, match="not a vision tower"):
-        native.check(tt.lib.grip_vit_forward(tt.handle, None, 0, None, 0, 1, None, None, 0, 0, None))
+        native.check(tt.lib.grip_vit_forward(tt.handle, None, 0, None, 0, 1, None, None, 0, 0, None, None))
     with pytest.raises(NotImplementedError):
         from grip_amd.models import CustomImageEncoder
         CustomImageEncoder(model.visual)(x, torch.zeros(2, 128, device="cuda"), deep_embds=torch.zeros(1))

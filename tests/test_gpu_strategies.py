@@ -115,3 +115,38 @@ def test_run_main_clip_baseline(tmp_path):
     assert res["model"] == "clip_baseline" and 0.0 <= res["test_accuracy"] <= 1.0 and res["n_test"] > 0
     line = json.loads(open(tmp_path / "results_model_clip_baseline.json").read().splitlines()[0])
     assert set(line) == {"model", "config", "accuracy"} and abs(line["accuracy"] - res["test_accuracy"]) < 1e-9
+
+
+@pytest.mark.parametrize("cls_name,paradigm", [("TextualFPL", "ssl"), ("VisualFPL", "ul"), ("MultimodalFPL", "trzsl")])
+def test_assign_pseudo_labels_uses_the_sharded_pool_encode(tmp_path, monkeypatch, cls_name, paradigm):
+    """GRIP's trained-model pass (the nine assign_pseudo_labels, e.g. transductive_zsl/multimodal_fpl.py:194-285): the pool
+    goes through pseudolabels.encode_pool (chunked + sharded, trained visual prompt included; mixer and text tower once per
+    call) and gives bit-identical features, hence identical lists, to the per-batch path the training loop uses."""
+    import grip_amd  # noqa: F401
+    from grip_amd import methods, pseudolabels as pl
+    from grip_amd.data import TensorPoolDataset
+    from grip_amd.methods.main import synthetic_pool
+    monkeypatch.chdir(tmp_path)
+    classes, files, images, names = synthetic_pool(5, 9, 64, 11)
+    l2i = {c: i for i, c in enumerate(classes)}
+    conf = _conf(MODEL="x", LEARNING_PARADIGM=paradigm, TEXT_PREFIX_SIZE=4, VISION_PREFIX_SIZE=4)
+    seen, unseen = (classes[:3], classes[3:]) if paradigm == "trzsl" else (classes, classes)
+    m = getattr(methods, cls_name)(conf, l2i, "", classes, seen, unseen, "cuda")
+    m.define_model(classes)
+    with torch.no_grad():    # move the prompts away from their init so a dropped prefix would show
+        for p in m.model.parameters():
+            if p.requires_grad:
+                p.add_(torch.randn_like(p) * 0.05)
+    data = TensorPoolDataset(files, images.cuda(), labels=None, label_map=l2i)
+    target = unseen if paradigm == "trzsl" else classes
+    calls = []
+    real = pl.encode_pool
+    monkeypatch.setattr(pl, "encode_pool", lambda *a, **k: (calls.append(k.get("prefix")), real(*a, **k))[1])
+    img, txt = m.trained_features(data.images, target, chunk=16)
+    assert len(calls) == 1 and (calls[0] is None) == (cls_name == "TextualFPL")
+    with torch.no_grad():
+        per_batch = [m.features(data.images[i:i + 16], target) for i in range(0, len(files), 16)]
+    assert torch.equal(img, torch.cat([f[0] for f in per_batch])) and torch.equal(txt, per_batch[0][1])
+    want = pl.pseudolabel_from_features(img, txt, m.scale(), list(data.filepaths), [l2i[c] for c in target], 3, argmax_on="logits")
+    out = m.assign_pseudo_labels(3, data)
+    assert (out.filepaths, out.labels) == want and out.label_id is True and len(want[0]) > 0

@@ -154,3 +154,75 @@ def test_result_helpers_follow_the_reference_schema(tmp_path, monkeypatch):
     assert len(lines) == 2 and lines[0]["accuracy"] == 4 / 6 and lines[0]["model"] == "textual_prompt" and lines[0]["config"]["LR"] == 0.1
     z = json.loads(open("results_model_grip_textual.json").read())
     assert set(z) == {"model", "config", "harmonic_mean", "seen_accuracy", "unseen_accuracy"} and z["unseen_accuracy"] == 0.5
+
+
+def test_fpl_balance_parameter_for_every_paradigm_and_modality():
+    """gamma of the FPL loss, 3 modalities x 3 paradigms: ssl |unseen| / |seen| (semi_supervised_learning/
+    textual_fpl.py:115, visual_fpl.py:110), trzsl |seen| / |unseen| (transductive_zsl/textual_fpl.py:109, visual_fpl.py:105),
+    square root of either for the multimodal strategies (semi_supervised_learning/multimodal_fpl.py:107,
+    transductive_zsl/multimodal_fpl.py:104), none for ul (unsupervised_learning/*_fpl.py: plain CE)."""
+    import math
+    import types
+
+    import grip_amd  # noqa: F401
+    from grip_amd.methods.training_strategies import TrainingStrategy
+    n_u, n_s = 32, 8     # pseudolabeled vs labeled images
+    want = {("ssl", "text"): n_u / n_s, ("ssl", "image"): n_u / n_s, ("ssl", "multi"): math.sqrt(n_u / n_s),
+            ("trzsl", "text"): n_s / n_u, ("trzsl", "image"): n_s / n_u, ("trzsl", "multi"): math.sqrt(n_s / n_u),
+            ("ul", "text"): 1.0, ("ul", "image"): 1.0, ("ul", "multi"): 1.0}
+    for (paradigm, modality), gamma in want.items():
+        me = object.__new__(TrainingStrategy)      # no GPU: only the host-side merge logic is exercised
+        me.config = types.SimpleNamespace(N_PSEUDOSHOTS=2, validation_seed=0, ratio_train_val=0.8)
+        me.paradigm, me.modality, me.label_to_idx = paradigm, modality, {"a": 0, "b": 1}
+        train = types.SimpleNamespace(filepaths=[f"s{i}.jpg" for i in range(n_s)], labels=["a"] * n_s, label_id=False)
+        unl = types.SimpleNamespace(filepaths=[f"u{i}.jpg" for i in range(n_u)], labels=[1] * n_u)
+        me.merge_pseudolabels(train, unl)
+        assert me.balance_param == pytest.approx(gamma), (paradigm, modality, me.balance_param)
+        assert len(train.filepaths) == (n_u if paradigm == "ul" else n_u + n_s) and train.label_id is True
+
+
+def test_on_disk_names_and_schemas_of_the_grip_artefacts(tmp_path, monkeypatch):
+    """utils/compute_metrics.py:105-171 of the reference: file names (incl. `_opt_{OPTIM_SEED}` in the pseudolabel file,
+    :152) and the eight positional UPT files `{base}_{name}.pt|.pickle` (:119-143).  The test writes with the product's
+    functions and reads the files back the way the reference's notebooks do (plain pickle.load / torch.load on the
+    reference's own f-string names), then the other way round through load_parameters."""
+    import pickle
+    import types
+
+    import numpy as np
+    import torch
+
+    import grip_amd  # noqa: F401
+    from grip_amd.utils import load_parameters, save_parameters, save_predictions, save_pseudo_labels
+    monkeypatch.chdir(tmp_path)
+    c = types.SimpleNamespace(DATASET_NAME="DTD", LEARNING_PARADIGM="trzsl", MODEL="grip_multimodal", VIS_ENCODER="ViT-B/16",
+                              OPTIM_SEED=3, SPLIT_SEED=500, MODALITY="multi")
+    enc = c.VIS_ENCODER.replace("/", "")
+    # pseudolabels (:150-154)
+    fn = save_pseudo_labels(["a.jpg", "b.jpg"], [4, 7], c, 2)
+    ref_name = f"pseudolabels/{c.DATASET_NAME}_{c.LEARNING_PARADIGM}_{c.MODEL}_{enc}_iter_2_opt_{c.OPTIM_SEED}_spl_{c.SPLIT_SEED}.pickle"
+    assert fn == ref_name == "pseudolabels/DTD_trzsl_grip_multimodal_ViT-B16_iter_2_opt_3_spl_500.pickle"
+    assert pickle.load(open(ref_name, "rb")) == {"filepaths": ["a.jpg", "b.jpg"], "labels": [4, 7]}
+    c2 = types.SimpleNamespace(**{**c.__dict__, "OPTIM_SEED": 4})
+    assert save_pseudo_labels([], [], c2, 2) != fn            # another optimisation seed does not overwrite it
+    # UPT parameters (:105-143): eight positional pieces, five torch-saved state_dicts + three pickled arrays
+    lin = torch.nn.Linear(4, 3)
+    obj = [{"w": torch.ones(2)}, lin.state_dict(), lin.state_dict(), lin.state_dict(), lin.state_dict(),
+           np.ones((1, 4, 8), np.float32), None, np.zeros((1, 4, 16), np.float32)]
+    files = save_parameters(obj, c, iteration=2)
+    base = f"trained_prompts/{c.DATASET_NAME}_{c.LEARNING_PARADIGM}_{c.MODEL}_{enc}_iter_2_opt_{c.OPTIM_SEED}_spl_{c.SPLIT_SEED}"
+    names = ["transformer", "proj_coop_pre", "proj_coop_post", "proj_vpt_pre", "proj_vpt_post", "coop_embeddings", "deep_vpt", "vpt_embeddings"]
+    assert files == [f"{base}_{n}.pt" for n in names[:5]] + [f"{base}_{n}.pickle" for n in names[5:]]
+    assert torch.equal(torch.load(f"{base}_proj_vpt_post.pt")["weight"], lin.weight)
+    assert pickle.load(open(f"{base}_deep_vpt.pickle", "rb")) is None
+    assert pickle.load(open(f"{base}_vpt_embeddings.pickle", "rb")).shape == (1, 4, 16)
+    back = load_parameters(c, iteration=2)
+    assert len(back) == 8 and torch.equal(back[0]["w"], torch.ones(2)) and back[6] is None and back[5].shape == (1, 4, 8)
+    # textual / visual prompt (:144-147) and predictions (:157-171): one pickle each, no iteration tag when iteration is None
+    t = types.SimpleNamespace(**{**c.__dict__, "MODEL": "textual_prompt", "MODALITY": "text"})
+    fn = save_parameters([np.ones((1, 16, 512), np.float32)], t)
+    assert fn == "trained_prompts/DTD_trzsl_textual_prompt_ViT-B16_opt_3_spl_500.pickle"
+    assert pickle.load(open(fn, "rb"))[0].shape == (1, 16, 512) and load_parameters(t)[0].shape == (1, 16, 512)
+    fn = save_predictions({"images": ["a"], "predictions": ["x"], "labels": ["x"], "logits": torch.zeros(1, 2)}, t, iteration=5)
+    assert fn == "evaluation/DTD_trzsl_textual_prompt_ViT-B16_iter_5_opt_3_spl_500.pickle"
+    assert set(pickle.load(open(fn, "rb"))) == {"images", "predictions", "labels", "logits"}
