@@ -44,7 +44,8 @@ F_IMG = 35.13e9          # algorithmic FLOPs per image, frozen ViT-B/16 forward 
 F_TXT = 5.96e9           # per class prompt, text tower forward (77 positions)
 PEAK_F16_TFLOPS = 2500.0 # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_16x16x4_f32), the exact mode's roof
-EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE"]
+EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE", "EPI_LNFOLD_F16",
+             "EPI_LNFOLD_GELU_F16", "EPI_BIAS_RESID_STATS"]
 TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
@@ -142,13 +143,13 @@ class Loop:
 
 
 # ------------------------------------------------------------------------------------------------ GEMM profiler helpers
-N_SLOTS = 56   # slot = variant * 8 + epilogue id (csrc/gemm.hip)
+N_SLOTS = 112   # slot = variant * 16 + epilogue id (csrc/gemm.hip)
 
 
 def kname(slot):
-    v, e = divmod(slot, 8)
+    v, e = divmod(slot, 16)
     return {1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
-            5: f"gemm_k64_kernel<{e}, 8>", 6: f"gemm_k64p_kernel<{e}>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e]}]"
+            5: f"gemm_k64_kernel<{e}, 8>", 6: f"gemm_k64p_kernel<{e}>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e] if e < len(EPI_NAMES) else e}]"
 
 
 def profile_collect(lib):

@@ -186,6 +186,25 @@ int grip_preprocess_image(const uint8_t* img, int H, int W,
 int grip_leaderboard_scan(const float* probs, const int32_t* pred, const int64_t* path_rank,
                           int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU exchange (one process per GPU, RCCL over the xGMI mesh).  The unlabeled pool shards contiguously over the
+ * ranks and the per-rank embeddings are all-gathered once per pass; this replaces the accelerator.gather
+ * sites of the reference (e.g. methods/semi_supervised_learning/textual_prompt.py:146-147, 285-286) and, for the trainable
+ * prompts, DDP's gradient all-reduce behind accelerator.backward (textual_prompt.py:131).
+ *   grip_comm_unique_id   rank 0 fills 128 bytes (an ncclUniqueId) and hands them to the other ranks through any side
+ *                         channel (torch.distributed store, a file, MPI)
+ *   grip_comm_init_rank   collective over the n_ranks processes; the calling thread's current HIP device is the rank's GPU
+ *   grip_allgather_embeddings   local [rows_per_rank, e] f32 device -> global [n_ranks * rows_per_rank, e] f32 device, rank-major
+ *                         (the caller pads the last shard to rows_per_rank rows and drops the padding afterwards)
+ *   grip_allreduce_mean   in place: every rank ends with the mean over ranks of grads[0..n)
+ * Both collectives are enqueued on `stream`.  RCCL is loaded at run time ($GRIP_RCCL_LIBRARY, else librccl.so). */
+typedef struct grip_comm grip_comm;
+int grip_comm_unique_id(uint8_t* id128);
+int grip_comm_init_rank(const uint8_t* id128, int n_ranks, int rank, grip_comm** out);
+int grip_comm_destroy(grip_comm* comm);
+int grip_allgather_embeddings(grip_comm* comm, const float* local, float* global, int64_t rows_per_rank, int e, void* stream);
+int grip_allreduce_mean(grip_comm* comm, float* grads, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

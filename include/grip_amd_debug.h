@@ -15,6 +15,15 @@ extern "C" {
  * A, W, resid and every output are f32 (epi 0..3 and 6 only). */
 int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid,
                     const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream);
+/* The LayerNorm-carrying epilogues (csrc/gemm.hip).  epi 3 with stat_part != NULL: the residual epilogue also writes, per row
+ * and 64-column tile, (sum, sum of squares) of the stored values to stat_part [M, N/64, 2].  epi 7 / 8: LayerNorm folded into
+ * the GEMM: out = [quickgelu](rstd_r (A W'^T - mean_r colsum) + bias) with rowstat [M, 2] = (mean, rstd), A = the raw rows. */
+int grip_debug_gemm_ln(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid, void* out, void* out2,
+                       float* stat_part, const float* rowstat, const float* colsum, int m_pad, int variant, void* stream);
+/* Wg = f16(gamma o W) [N, K], colsum[n] = sum_k Wg[n][k], bias_out = bias + W beta; then, if stat_part != NULL,
+ * rowstat [M, 2] = (mean, rstd) from the [M, parts, 2] partial sums over rows of width d. */
+int grip_debug_ln_fold(const void* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* colsum, float* bias_out,
+                       int N, int K, const float* stat_part, int parts, float* rowstat, int M, int d, void* stream);
 /* out[B*S, H*64] = softmax(q k^T / 8 [+ causal mask]) v for qkv[B*S, 3*H*64] (f16). */
 int grip_debug_attention(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
 /* The same in f32 (exact mode, csrc/attention_f32.hip): qkv and out f32, any S. */

@@ -52,6 +52,13 @@ enum GemmEpi {
     EPI_F16 = 4,             // out_f16 = acc
     EPI_GELUGRAD_F16 = 5,    // out_f16 = acc * quickgelu'(aux_f16)       (backward of c_fc activation)
     EPI_F32_SCALE = 6,       // out_f32 = acc * scalar
+    // LayerNorm folded into the GEMM that consumes it (A = the RAW residual stream, W = gamma-scaled weights W' = f16(gamma o W)):
+    //   LN(x) W^T + b  =  rstd_r * (x W'^T - mean_r * colsum(W')) + (W beta + b)
+    // rowstat[r] = (mean_r, rstd_r), colsum[n] = sum_k W'[n][k], bias[n] = (W beta + b)[n]
+    EPI_LNFOLD_F16 = 7,      // out_f16 = rstd * (acc - mean * colsum) + bias
+    EPI_LNFOLD_GELU_F16 = 8, // out_f16 = quickgelu(that); if out2 != null, out2_f16 = that (pre-activation)
+    EPI_BIAS_RESID_STATS = 9,// EPI_BIAS_RESID + the row statistics (GemmArgs.stat_part); chosen by the launcher, never passed in by callers
+    EPI_COUNT = 10
 };
 
 #ifdef __HIPCC__
@@ -86,6 +93,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
     return (r0 + r1) + (r2 + r3);
+}
+// Sum over each 16-lane row of the wave (the four DPP steps above), returned in every lane of the row.
+__device__ __forceinline__ float row16_sum(float v) {
+#define GRIP_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    GRIP_DPP_ADD(0xB1);
+    GRIP_DPP_ADD(0x4E);
+    GRIP_DPP_ADD(0x141);
+    GRIP_DPP_ADD(0x140);
+#undef GRIP_DPP_ADD
+    return v;
 }
 
 __device__ __forceinline__ f32x4 load4(const float* p, int i) { return ((const f32x4*)p)[i]; }
@@ -136,6 +153,11 @@ struct GemmArgs {
     int ldc;
     float scalar;
     int f32;            // 1 = exact mode: A, W, resid and every activation output are f32 (gemm_f32.hip, v_mfma_f32_16x16x4_f32)
+    // LayerNorm statistics travelling with the residual stream (f16 towers):
+    float* stat_part;      // EPI_BIAS_RESID, optional: [M, N/64, 2] per-row partial (sum, sum of squares) of the values written, one pair
+                           // per 64-column wave tile; ln_stats_finalize turns them into rowstat for the consuming GEMM
+    const float* rowstat;  // EPI_LNFOLD_*: [M, 2] (mean, rstd) of A's rows
+    const float* colsum;   // EPI_LNFOLD_*: [N]
 };
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
@@ -145,12 +167,17 @@ int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);
 // row-wise kernels (rowops.hip)
 int launch_im2col(const void* images, int images_f16, void* out, int out_f32, int B, int R, int patch, int Kpad, hipStream_t s);
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, void* x, int f32, int B, int G2, int d, hipStream_t s);
+                           const float* gamma, const float* beta, void* x, int f32, float* rowstat, int B, int G2, int d, hipStream_t s);
+// rowstat [M, 2] = (mean, rstd) of every row from the [M, parts, 2] partial sums the residual GEMM epilogues emit
+int launch_ln_stats_finalize(const float* stat_part, int parts, float* rowstat, int M, int d, hipStream_t s);
+// W' = f16(gamma o W) [N, K]; colsum[n] = sum_k W'[n][k]; bias_out[n] = bias[n] + sum_k beta[k] W[n][k]
+int launch_ln_fold_weights(const half_t* W, const float* gamma, const float* beta, const float* bias, half_t* Wg, float* colsum, float* bias_out,
+                           int N, int K, hipStream_t s);
 int launch_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int f32, int M, int d, hipStream_t s);
 int launch_gather_ln_f16(const void* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
                          void* out, int f32, int n_rows, int d, hipStream_t s);
 int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, void* x, int f32, int C, int T, int d, int vocab, hipStream_t s);
+                      int prefix_classes, void* x, int f32, float* rowstat, int C, int T, int d, int vocab, hipStream_t s);
 int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int ld_in, hipStream_t s);
 
 // attention (attention.hip / attention_f32.hip): qkv [B*S, 3*D] -> out [B*S, D]

@@ -53,7 +53,7 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 // element in the epilogue.
 template <int EPI, int ROWFRAGS>
 __device__ __forceinline__ void init_acc(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], int col0, int lane) {
-    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID);
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_STATS);
     if constexpr (HAS_BIAS) {
         f32x4 b[4];
 #pragma unroll
@@ -84,14 +84,17 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
     constexpr int NP = ROWFRAGS / PF;
     constexpr int RP = 16 * PF;        // rows per pass
     constexpr int NI = 4 * PF;         // row groups (4 rows each) per pass
+    constexpr bool FOLD = (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16);
+    constexpr bool RESID = (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_STATS);
     const int frow = lane & 15, fgrp = lane >> 4;
     const int rr = lane >> 4, cc = (lane & 15) * 4;
     const int col = col0 + cc;
     const int ldc = g.ldc;
-    // operand prefetch (residual / GELU' argument): all 8 row loads of a pass are issued together, and
+    // operand prefetch (residual / GELU' argument / row statistics): all row loads of a pass are issued together, and
     // the loads of pass p+1 go out before the stores of pass p, so no load ever queues behind a store.
     half4 res[2][NI];
     half4 aux[2][NI];
+    float2 rst[2][NI];
     // Addresses: one 32-bit element offset per lane plus a wave-uniform step per row group, against the uniform base
     // pointers (saddr + voffset addressing, one VGPR per access).  With 64-bit per-row pointers the compiler materialises
     // all 64 of them at the top of the epilogue and spills them when the main loop leaves < 10 free registers.
@@ -109,18 +112,28 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const uint32_t o = elem_off(p, it);
-            if constexpr (EPI == EPI_BIAS_RESID) res[b][it] = *(const half4*)((const half_t*)g.resid + o);
+            if constexpr (RESID) res[b][it] = *(const half4*)((const half_t*)g.resid + o);
             if constexpr (EPI == EPI_GELUGRAD_F16) aux[b][it] = *(const half4*)((const half_t*)g.aux + o);
+            if constexpr (FOLD) {
+                int row = row0 + p * RP + it * 4 + rr;
+                if constexpr (CHECK) row = row < g.M ? row : g.M - 1;
+                rst[b][it] = ((const float2*)g.rowstat)[row];      // the 16 lanes of a row read one address: a broadcast load
+            }
         }
     };
-    if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_GELUGRAD_F16) prefetch(0, 0);
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f}, bfold = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FOLD) {
+        csum = *(const f32x4*)(g.colsum + col);
+        bfold = *(const f32x4*)(g.bias + col);
+    }
+    if constexpr (RESID || EPI == EPI_GELUGRAD_F16 || FOLD) prefetch(0, 0);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int ii = 0; ii < PF; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(f32x4*)(slab + slab_off<PF>(ii * 16 + frow, j * 4 + fgrp)) = acc[PF * p + ii][j];
-        if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_GELUGRAD_F16)
+        if constexpr (RESID || EPI == EPI_GELUGRAD_F16 || FOLD)
             if (p + 1 < NP) prefetch(p + 1, (p + 1) & 1);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -129,20 +142,38 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
             f32x4 v = *(const f32x4*)(slab + slab_off<PF>(rl, lane & 15));
             const int row = row0 + p * RP + rl;
             const uint32_t o = CHECK ? (uint32_t)row * (uint32_t)ldc + (uint32_t)col : elem_off(p, it);
+            if constexpr (RESID) {
+                // the add into the residual stream happens here in f32; the row statistics of what is about to be stored travel
+                // with it (per 64-column wave tile), so the LayerNorm that follows never has to re-read the stream
+                const half4 rh = res[p & 1][it];
+                v += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                if constexpr (EPI == EPI_BIAS_RESID_STATS) {
+                    const float sm = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+                    const float sq = row16_sum(__builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3]))));
+                    if ((lane & 15) == 0 && (!CHECK || row < g.M))
+                        ((float2*)g.stat_part)[(uint32_t)row * (uint32_t)(g.N >> 6) + (uint32_t)(col0 >> 6)] = make_float2(sm, sq);   // M * N / 64 < 2^31
+                }
+            }
             if (!CHECK || row < g.M) {
                 if constexpr (EPI == EPI_F32) {
                     *(f32x4*)((float*)g.out + o) = v;
                 } else if constexpr (EPI == EPI_F32_SCALE) {
                     *(f32x4*)((float*)g.out + o) = v * g.scalar;
-                } else if constexpr (EPI == EPI_BIAS_RESID) {
-                    const half4 rh = res[p & 1][it];
-                    v += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                } else if constexpr (RESID) {
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_F16) {
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_BIAS_GELU_F16) {
                     if (g.out2) *(half4*)((half_t*)g.out2 + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)quick_gelu(v[0]), (half_t)quick_gelu(v[1]), (half_t)quick_gelu(v[2]), (half_t)quick_gelu(v[3])};
+                } else if constexpr (FOLD) {
+                    const float2 st = rst[p & 1][it];
+                    v = (v - csum * st.x) * st.y + bfold;
+                    if constexpr (EPI == EPI_LNFOLD_GELU_F16) {
+                        if (g.out2) *(half4*)((half_t*)g.out2 + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        v = (f32x4){quick_gelu(v[0]), quick_gelu(v[1]), quick_gelu(v[2]), quick_gelu(v[3])};
+                    }
+                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_GELUGRAD_F16) {
                     const half4 x = aux[p & 1][it];
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)(v[0] * quick_gelu_grad((float)x[0])), (half_t)(v[1] * quick_gelu_grad((float)x[1])),
@@ -319,7 +350,7 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     const int b_off = BMT * BK2 + (wc * 64 + frow) * BK2 + fchunk * 8;
 
     f32x4 acc[8][4];
-    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID) {
+    if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_STATS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 b = *(const f32x4*)(g.bias + n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
@@ -448,7 +479,9 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     }
 
     __builtin_amdgcn_s_barrier();   // every wave is done with the ring: reuse it as epilogue slabs
-    epilogue_rows<EPI, 8>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * 64, lane);
+    // (the statistics-carrying and LayerNorm-folded epilogues hold more per-row operands: 16-row passes keep their prefetch within
+    // the register budget -- with 32-row passes the 256x128 kernel spilled six dwords and returned wrong values in its last row group)
+    epilogue_rows<EPI, 8, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 // ---- 256x256 tile, K staged 64 wide: every DMA instruction moves 8 rows x 128 B, i.e. whole cache lines (the 32-wide
@@ -560,7 +593,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
     __builtin_amdgcn_s_barrier();   // every wave is done with the stages: reuse them as epilogue slabs
 #pragma unroll
     for (int h = 0; h < NJ / 4; ++h)
-        epilogue_rows<EPI, 8>(g, acc[h], (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * WCOLS + h * 64, lane);
+        epilogue_rows<EPI, 8, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc[h], (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * WCOLS + h * 64, lane);
 }
 
 // ---- Persistent form of gemm_k64_kernel: one workgroup per CU walks its XCD's run of tiles, and the two-stage K pipeline
@@ -569,7 +602,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
 // (~2 us of a ~32 us K = 768 tile) nor ends with an idle DMA queue.  The epilogue slabs therefore cannot reuse the stage
 // buffers: they are 16-row, 4 KiB, swizzled slabs in the 32 KiB of LDS beside the two 64 KiB stages.
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m, int tiles_n, int colgroup) {
     constexpr int BMT = 256, BNT = 256, NW = 8, WN = 4;
     constexpr int STAGE = (BMT + BNT) * BK;       // halfs per stage (BK = 64)
     constexpr int GI = (BMT + BNT) / 8 / NW;      // DMA instructions per wave per stage
@@ -581,23 +614,55 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     const int wr = wave / WN, wc = wave - wr * WN;
     float* slab = (float*)(lds2 + 2 * STAGE) + wave * 1024;
 
-    // XCD x (= blockIdx & 7) owns the contiguous tile run [xstart, xstart + xcount), N-fastest; its workgroups take the
-    // run's tiles round-robin, so the 32 tiles in flight on an XCD are consecutive as in the one-tile-per-workgroup launch.
-    const int nwg = tiles_m * tiles_n;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
-    const int xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
-    const int xcount = xq + (xcd < xr ? 1 : 0);
+    // Tile walk.  XCD x (= blockIdx & 7; its own 4 MiB L2) owns a contiguous band of ROW panels; inside the band the tiles
+    // are ordered column group by column group (colgroup tiles wide), rows fastest after the group's columns:
+    //     for cg: for row in band: for c in cg's columns: tile (row, c)
+    // and the XCD's workgroups take them round-robin, so the 32 tiles in flight on an XCD are (32 / colgroup) row panels x
+    // colgroup column panels.  The W panels of one column group (colgroup x 256 x K halfs: 1.5 MB for 4 x K = 768) then stay
+    // L2-resident for the whole sweep down the band while A panels stream through once per group.  With colgroup = tiles_n
+    // this is the plain N-fastest walk, under which the 4.7 MB of c_fc's twelve W panels were re-fetched from the memory
+    // side for every few row panels (round 1: 4.3 GB of fetches per launch against 0.4 GB of A).
+    // colgroup = 0 (launches with fewer than 64 row panels, where whole-row bands would load the XCDs unevenly): the XCD owns a
+    // contiguous run of tiles, N-fastest, split evenly at tile granularity.
+    const int xcd = blockIdx.x & 7;
     const int per_xcd = gridDim.x >> 3;
+    int row_start, nrows, xstart = 0, xcount, group_tiles = 1;
+    if (colgroup > 0) {
+        const int rows_q = tiles_m >> 3, rows_r = tiles_m & 7;
+        row_start = xcd < rows_r ? xcd * (rows_q + 1) : rows_r * (rows_q + 1) + (xcd - rows_r) * rows_q;
+        nrows = rows_q + (xcd < rows_r ? 1 : 0);
+        xcount = nrows * tiles_n;
+        group_tiles = nrows * colgroup;
+    } else {
+        const int nwg = tiles_m * tiles_n;
+        const int xq = nwg >> 3, xr = nwg & 7;
+        xstart = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+        xcount = xq + (xcd < xr ? 1 : 0);
+        row_start = 0;
+        nrows = 0;
+    }
     int t = blockIdx.x >> 3;
     if (t >= xcount) return;
+    auto tile_coords = [&](int tile, int& tm, int& tn) {
+        if (colgroup > 0) {
+            const int cg = tile / group_tiles, rem = tile - cg * group_tiles;
+            const int r = rem / colgroup;
+            tm = row_start + r;
+            tn = cg * colgroup + (rem - r * colgroup);
+        } else {
+            const int bid = xstart + tile;
+            tm = bid / tiles_n;
+            tn = bid - tm * tiles_n;
+        }
+    };
 
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
     const int r0 = wave * GI * 8;
     auto tile_src = [&](int tile) {
-        const int bid = xstart + tile;
-        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        int tm, tn;
+        tile_coords(tile, tm, tn);
         return (r0 < BMT ? (const half_t*)g.A + (size_t)(tm * BMT + r0 + srow) * K : (const half_t*)g.W + (size_t)(tn * BNT + r0 - BMT + srow) * K) + schunk * 8;
     };
     auto stage = [&](int buf, const half_t* src, int kt) {
@@ -649,13 +714,13 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     __builtin_amdgcn_s_barrier();
     int par = 0;                // LDS slot of the current tile's stage 0
     for (;;) {
-        const int bid = xstart + t;
-        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+        int tm, tn;
+        tile_coords(t, tm, tn);
         const int m0 = tm * BMT, n0 = tn * BNT;
         const int t_next = t + per_xcd;
         const bool has_next = t_next < xcount;
         const half_t* src_next = has_next ? tile_src(t_next) : src_cur;
-        if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID) {
+        if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_STATS) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 b = *(const f32x4*)(g.bias + n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
@@ -697,7 +762,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
 #include <deque>
 #include <vector>
 namespace {
-constexpr int PROF_RING = 4096, PROF_EPIS = 56;   // slot = variant * 8 + epilogue id (variants 1..6)
+constexpr int PROF_RING = 4096, PROF_EPIS = 112;   // slot = variant * 16 + epilogue id (variants 1..6)
 struct ProfRec { int epi; double flops; hipEvent_t a, b; };
 bool g_prof = false;
 std::deque<ProfRec> g_recs;
@@ -733,7 +798,7 @@ extern "C" int grip_profile_enable(int on) {
     return GRIP_OK;
 }
 
-// Per slot (variant * 8 + epilogue id) in [0, n): launches[slot], total milliseconds, total algorithmic FLOPs (2*M*N*K) of
+// Per slot (variant * 16 + epilogue id) in [0, n): launches[slot], total milliseconds, total algorithmic FLOPs (2*M*N*K) of
 // every GEMM launched since grip_profile_enable(1).  Synchronises the outstanding events.
 extern "C" int grip_profile_collect(int n, int64_t* launches, double* total_ms, double* total_flops) {
     prof_drain(0);
@@ -760,7 +825,7 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     (void)hipEventRecord(r.a, s);
     const int rc = launch_gemm_impl(epi, a, s, &chosen);
     (void)hipEventRecord(r.b, s);
-    r.epi = chosen * 8 + epi;
+    r.epi = chosen * 16 + epi;
     g_recs.push_back(r);
     return rc;
 }
@@ -788,6 +853,9 @@ static int launch_big(int epi, const GemmArgs& a, hipStream_t s) {
         GRIP_GEMM_CASE(EPI_F16)
         GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
         GRIP_GEMM_CASE(EPI_F32_SCALE)
+        GRIP_GEMM_CASE(EPI_LNFOLD_F16)
+        GRIP_GEMM_CASE(EPI_LNFOLD_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_STATS)
         default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
     }
 #undef GRIP_GEMM_CASE
@@ -817,6 +885,8 @@ static int launch_k64(int epi, const GemmArgs& a, hipStream_t s) {
         GRIP_GEMM_CASE(EPI_F16)
         GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
         GRIP_GEMM_CASE(EPI_F32_SCALE)
+        GRIP_GEMM_CASE(EPI_LNFOLD_F16)
+        GRIP_GEMM_CASE(EPI_LNFOLD_GELU_F16)
         default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
     }
 #undef GRIP_GEMM_CASE
@@ -836,7 +906,22 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
         GRIP_REQUIRE(n_cu >= 8, "gemm: device reports %d CUs", n_cu);
     }
     const int tiles = tiles_m * tiles_n;
-    const int grid_n = tiles >= n_cu ? n_cu : ((tiles + 7) & ~7);
+    // every XCD owns ceil or floor(tiles_m / 8) row panels: the grid has enough workgroups per XCD for the largest band
+    const int band = ((tiles_m + 7) / 8) * tiles_n;
+    // Tile walk: the even N-fastest split (colgroup = 0) is the default.  The row-band / column-group walk (see the kernel) cuts
+    // the memory-side fetches of the K = 768 GEMMs by keeping one group's W panels L2-resident, but measured SLOWER on the
+    // pool encode (r02: c_fc 794 vs 839 TF/s, QKV 891 vs 922 with groups of 4 / 3 column tiles): the refetched W panels come
+    // out of the 256 MiB Infinity Cache, not HBM, and the banded walk makes all 32 workgroups of an XCD start their tiles'
+    // A panels at once.  GRIP_GEMM_COLGROUP=<n> (a divisor of N / 256; 1 = tiles_n wide bands) switches it on for A/B runs.
+    static const int force_cg = getenv("GRIP_GEMM_COLGROUP") ? atoi(getenv("GRIP_GEMM_COLGROUP")) : 0;
+    int colgroup = 0;
+    if (force_cg > 0 && tiles_m >= 64) {
+        colgroup = tiles_n;
+        if (a.K <= 1024 && force_cg > 1)
+            for (int c = force_cg; c >= 2; --c)
+                if (tiles_n % c == 0 && tiles_n > c) { colgroup = c; break; }
+    }
+    const int grid_n = colgroup ? (band * 8 >= n_cu ? n_cu : band * 8) : (tiles >= n_cu ? n_cu : ((tiles + 7) & ~7));
     dim3 grid(grid_n), block(512);
 #define GRIP_GEMM_CASE(E)                                                                                                   \
     case E: {                                                                                                               \
@@ -845,7 +930,7 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
             GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64p_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             configured = true;                                                                                              \
         }                                                                                                                   \
-        hipLaunchKernelGGL((gemm_k64p_kernel<E>), grid, block, lds, s, a, tiles_m, tiles_n);                                \
+        hipLaunchKernelGGL((gemm_k64p_kernel<E>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                                \
     } break;
     switch (epi) {
         GRIP_GEMM_CASE(EPI_F32)
@@ -855,6 +940,9 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
         GRIP_GEMM_CASE(EPI_F16)
         GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
         GRIP_GEMM_CASE(EPI_F32_SCALE)
+        GRIP_GEMM_CASE(EPI_LNFOLD_F16)
+        GRIP_GEMM_CASE(EPI_LNFOLD_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_STATS)
         default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
     }
 #undef GRIP_GEMM_CASE
@@ -865,6 +953,8 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
 // variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage ring), 3 = 256x128x32 (3-stage ring), 4 = 64x128x64 (2-stage),
 //          5 = 256x256x64 (2-stage, whole-line DMA), 6 = the same, persistent
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
+    if (epi == EPI_BIAS_RESID && a.stat_part) epi = EPI_BIAS_RESID_STATS;
+    GRIP_REQUIRE(epi != EPI_BIAS_RESID_STATS || (a.stat_part && a.N % 64 == 0), "gemm: row statistics need stat_part and N %% 64 == 0");
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 4 == 0, "gemm: ldc %% 4 != 0");
     GRIP_REQUIRE(((int64_t)a.M + 256) * a.ldc < ((int64_t)1 << 31), "gemm: output larger than 2^31 elements (M=%d ldc=%d)", a.M, a.ldc);
@@ -894,6 +984,7 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
             }
         }
     }
+    if (variant == 5 && epi == EPI_BIAS_RESID_STATS) variant = 6;   // the one-tile-per-workgroup 64-wide kernel has no registers left for the statistics
     *chosen = variant;
     if (variant == 2) {
         GRIP_REQUIRE(can_big && a.N % 256 == 0, "gemm: 256x256 tile needs N %% 256 == 0 and A padded to 256 rows");
@@ -927,6 +1018,9 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
         GRIP_GEMM_CASE(EPI_F16)
         GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
         GRIP_GEMM_CASE(EPI_F32_SCALE)
+        GRIP_GEMM_CASE(EPI_LNFOLD_F16)
+        GRIP_GEMM_CASE(EPI_LNFOLD_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_STATS)
         default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
     }
 #undef GRIP_GEMM_CASE

@@ -84,7 +84,7 @@ template <int NV, typename RT>
 __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ prefix, int P,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              RT* __restrict__ x, int B, int G2, int d) {
+                                                              RT* __restrict__ x, float* __restrict__ rowstat, int B, int G2, int d) {
     const int lane = threadIdx.x & 63;
     const int S = 1 + P + G2;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -110,17 +110,22 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
             const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], bb = ((const f32x4*)beta)[lane + 64 * i];
-            store4(o, lane + 64 * i, ln_apply(v[i], mean, rstd, g, bb));
+            v[i] = ln_apply(v[i], mean, rstd, g, bb);
+            store4(o, lane + 64 * i, v[i]);
         }
+    if (rowstat) {     // statistics of the row just written, for the LayerNorm folded into the first QKV GEMM
+        ln_normalize<NV>(v, lane, d4, d, mean, rstd);
+        if (lane == 0) ((float2*)rowstat)[row] = make_float2(mean, rstd);
+    }
 }
 
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, void* x, int f32, int B, int G2, int d, hipStream_t s) {
+                           const float* gamma, const float* beta, void* x, int f32, float* rowstat, int B, int G2, int d, hipStream_t s) {
     const int rows = B * (1 + P + G2);
     if (f32) {
-        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, float>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (float*)x, B, G2, d));
+        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, float>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (float*)x, rowstat, B, G2, d));
     } else {
-        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, resid_t>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (resid_t*)x, B, G2, d));
+        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, resid_t>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (resid_t*)x, rowstat, B, G2, d));
     }
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
@@ -131,7 +136,7 @@ int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float
 template <typename RT>
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, int ld_ids, const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, const float* __restrict__ prefix, int P,
-                                                         int prefix_classes, RT* __restrict__ x, int C, int T, int d, int vocab) {
+                                                         int prefix_classes, RT* __restrict__ x, float* __restrict__ rowstat, int C, int T, int d, int vocab) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= C * T) return;
@@ -147,16 +152,27 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
     }
     const f32x4* pp = (const f32x4*)(pos + (size_t)t * d);
     RT* o = x + (size_t)row * d;
-    for (int f = lane; f < d4; f += 64) store4(o, f, src[f] + pp[f]);
+    float sm = 0.f, sq = 0.f;
+    for (int f = lane; f < d4; f += 64) {
+        const f32x4 v = src[f] + pp[f];
+        store4(o, f, v);
+        sm += (v[0] + v[1]) + (v[2] + v[3]);
+        sq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (rowstat) {     // (mean, rstd) of the row, for the LayerNorm folded into the first QKV GEMM
+        const float mean = wave_sum(sm) / (float)d;
+        const float var = fmaxf(wave_sum(sq) / (float)d - mean * mean, 0.f);
+        if (lane == 0) ((float2*)rowstat)[row] = make_float2(mean, rsqrtf(var + LN_EPS));
+    }
 }
 
 int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, void* x, int f32, int C, int T, int d, int vocab, hipStream_t s) {
+                      int prefix_classes, void* x, int f32, float* rowstat, int C, int T, int d, int vocab, hipStream_t s) {
     GRIP_REQUIRE(d % 4 == 0, "text_embed: width %% 4 != 0");
     if (f32)
-        hipLaunchKernelGGL(text_embed_kernel<float>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (float*)x, C, T, d, vocab);
+        hipLaunchKernelGGL(text_embed_kernel<float>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (float*)x, rowstat, C, T, d, vocab);
     else
-        hipLaunchKernelGGL(text_embed_kernel<resid_t>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (resid_t*)x, C, T, d, vocab);
+        hipLaunchKernelGGL(text_embed_kernel<resid_t>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (resid_t*)x, rowstat, C, T, d, vocab);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
@@ -254,6 +270,61 @@ int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int
         hipLaunchKernelGGL(transpose_kernel<float>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, (const float*)in, (float*)out, rows, cols, ld_in);
     else
         hipLaunchKernelGGL(transpose_kernel<half_t>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, (const half_t*)in, (half_t*)out, rows, cols, ld_in);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm folded into its consumer GEMM (EPI_LNFOLD_*, gemm.hip).
+// (1) Row statistics: the residual GEMM epilogues emit, per row and 64-column wave tile, (sum, sum of squares) of the values they
+//     store; one thread per row adds the d/64 pairs in a fixed order and turns them into (mean, rstd).  96 B in, 8 B out per row
+//     at d = 768 -- against 2 x 1 536 B for a stand-alone LayerNorm pass over the stream.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int parts, float* __restrict__ rowstat, int M, float inv_d) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float2* p = (const float2*)part + (size_t)row * parts;
+    float sm = 0.f, sq = 0.f;
+    for (int i = 0; i < parts; ++i) {
+        const float2 v = p[i];
+        sm += v.x;
+        sq += v.y;
+    }
+    const float mean = sm * inv_d;
+    const float var = fmaxf(sq * inv_d - mean * mean, 0.f);
+    ((float2*)rowstat)[row] = make_float2(mean, rsqrtf(var + LN_EPS));
+}
+
+int launch_ln_stats_finalize(const float* stat_part, int parts, float* rowstat, int M, int d, hipStream_t s) {
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, s, stat_part, parts, rowstat, M, 1.0f / (float)d);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+// (2) Weights, once per tower (grip_tower_finalize): W'[n][k] = f16(gamma[k] * W[n][k]), colsum[n] = sum_k W'[n][k] (of the ROUNDED
+//     values, so that mean * colsum cancels the mean part of x W'^T exactly as accumulated), bias_out[n] = bias[n] + sum_k beta[k] W[n][k].
+//     One wave per output row.
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const half_t* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ bias, half_t* __restrict__ Wg, float* __restrict__ colsum,
+                                                              float* __restrict__ bias_out, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float cs = 0.f, bb = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(size_t)n * K + k];
+        const half_t wg = (half_t)(gamma[k] * w);
+        Wg[(size_t)n * K + k] = wg;
+        cs += (float)wg;
+        bb += beta[k] * w;
+    }
+    cs = wave_sum(cs);
+    bb = wave_sum(bb);
+    if (lane == 0) { colsum[n] = cs; bias_out[n] = bias[n] + bb; }
+}
+
+int launch_ln_fold_weights(const half_t* W, const float* gamma, const float* beta, const float* bias, half_t* Wg, float* colsum, float* bias_out,
+                           int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, gamma, beta, bias, Wg, colsum, bias_out, N, K);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -32,8 +32,10 @@ struct LayerW {
     // f16 (element offsets into the f16 blob)
     int64_t in_w, out_w, fc_w, proj_w;          // [3d,d] [d,d] [4d,d] [d,4d]
     int64_t in_wT, out_wT, fc_wT, proj_wT;      // derived transposes: [d,3d] [d,d] [d,4d] [4d,d]
+    int64_t in_wG, fc_wG;                       // derived: LayerNorm-folded operands f16(gamma o W) of the QKV and c_fc GEMMs
     // f32
     int64_t ln1_g, ln1_b, in_b, out_b, ln2_g, ln2_b, fc_b, proj_b;
+    int64_t in_cs, in_bb, fc_cs, fc_bb;         // derived: colsum(W') and W beta + b of the two folded GEMMs
 };
 struct Layout {
     std::vector<grip_slot> slots;
@@ -104,6 +106,12 @@ static int build_layout(const grip_dims& D, Layout& L) {
         w.out_wT = add_slot(L, p + "attn.out_proj.weight#T", 0, 1, d, d);
         w.fc_wT = add_slot(L, p + "mlp.c_fc.weight#T", 0, 1, d, 4 * d);
         w.proj_wT = add_slot(L, p + "mlp.c_proj.weight#T", 0, 1, 4 * d, d);
+        w.in_wG = add_slot(L, p + "attn.in_proj_weight#G", 0, 1, 3 * d, d);
+        w.fc_wG = add_slot(L, p + "mlp.c_fc.weight#G", 0, 1, 4 * d, d);
+        w.in_cs = add_slot(L, p + "attn.in_proj#colsum", 1, 1, 1, 3 * d);
+        w.in_bb = add_slot(L, p + "attn.in_proj#bias", 1, 1, 1, 3 * d);
+        w.fc_cs = add_slot(L, p + "mlp.c_fc#colsum", 1, 1, 1, 4 * d);
+        w.fc_bb = add_slot(L, p + "mlp.c_fc#bias", 1, 1, 1, 4 * d);
     }
     const char* lnf = D.kind == 0 ? "ln_post" : "ln_final";
     L.lnpost_g = add_slot(L, std::string(lnf) + ".weight", 1, 0, 1, d);
@@ -154,6 +162,8 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     half_t* cls16 = nullptr;   // [round_up(batch,128), d]
     half_t* patches = nullptr; // alias of h
     float* patch_out = nullptr;// alias of qkv
+    float* stat_part = nullptr;// [Mp, d/64, 2] partial row sums emitted by the residual GEMM epilogues (f16 towers)
+    float* rowstat = nullptr;  // [Mp, 2] (mean, rstd) of the residual stream's rows, consumed by the LayerNorm-folded GEMMs
     // train-mode saves, one per layer (x_in has layers+1 entries)
     std::vector<resid_t*> x_in, x_mid;
     std::vector<half_t*> qkv_l, att_l, hpre_l;
@@ -215,6 +225,10 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * es); w.att = (half_t*)take(w.Mp * d * es); }
     w.h = (half_t*)take(w.Mp * 4 * d * es);
     w.cls16 = (half_t*)take(Bp * d * es);
+    if (!t->f32) {
+        w.stat_part = (float*)take(w.Mp * (d / 64) * 2 * sizeof(float));
+        w.rowstat = (float*)take(w.Mp * 2 * sizeof(float));
+    }
     if (D.kind == 0) {
         const int64_t G2 = D.seq0 - 1;
         const int64_t prow = round_up64(batch * G2, 256);
@@ -280,6 +294,12 @@ extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
             if ((rc = launch_transpose(t->wop(w.fc_w), t->wop(w.fc_wT), f, 4 * d, d, d, s))) return rc;
             if ((rc = launch_transpose(t->wop(w.proj_w), t->wop(w.proj_wT), f, d, 4 * d, 4 * d, s))) return rc;
         }
+    if (!f)       // LayerNorm-folded operands of the QKV and c_fc GEMMs (EPI_LNFOLD_*): W' = f16(gamma o W), colsum(W'), W beta + b
+        for (const LayerW& w : t->L.layer) {
+            float* F = t->w32;
+            if ((rc = launch_ln_fold_weights(t->w16 + w.in_w, F + w.ln1_g, F + w.ln1_b, F + w.in_b, t->w16 + w.in_wG, F + w.in_cs, F + w.in_bb, 3 * d, d, s))) return rc;
+            if ((rc = launch_ln_fold_weights(t->w16 + w.fc_w, F + w.ln2_g, F + w.ln2_b, F + w.fc_b, t->w16 + w.fc_wG, F + w.fc_cs, F + w.fc_bb, 4 * d, d, s))) return rc;
+        }
     if ((rc = launch_transpose(t->wop(t->L.proj), t->wop(t->L.projT), f, d, t->D.embed_dim, t->D.embed_dim, s))) return rc;
     t->finalized = true;
     return GRIP_OK;
@@ -299,33 +319,56 @@ extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix
 // ---------------------------------------------------------------------------------------------- forward
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// One tower pass over the residual stream.  f16 towers never run a stand-alone LayerNorm inside the blocks: the statistics of
+// every row travel with the stream -- the assembly / embedding kernel writes (mean, rstd) of x0, each residual GEMM epilogue
+// emits the partial sums of the rows it stores and a 104-byte-per-row kernel finalises them -- and ln_1 / ln_2 are folded
+// into the QKV / c_fc GEMMs, whose A operand is the raw stream (EPI_LNFOLD_*: rstd (x W'^T - mean colsum(W')) + (W beta + b)).
+// That removes two full read + write passes over the stream per block (8.8 % of the pool encode's GPU time in round 1).
+// Exact (f32) towers keep the literal LayerNorm -> GEMM sequence.
 static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipStream_t s, resid_t** x_final) {
     const int d = t->D.width, H = t->D.heads, f = t->f32;
     const float* F = t->w32;
     resid_t* x = x0;
+    const int parts = d / 64;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
+        const bool last = l + 1 == t->D.layers;
         half_t* qkv = w.train ? w.qkv_l[(size_t)l] : w.qkv;
         half_t* att = w.train ? w.att_l[(size_t)l] : w.att;
         resid_t* x_mid = w.train ? w.x_mid[(size_t)l] : x;
         resid_t* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
-        RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, f, w.M, d, s));
         GemmArgs a{};
-        a.f32 = f; a.A = w.xn; a.W = t->wop(lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
-        RUN(launch_gemm(EPI_BIAS_F16, a, s));
-        if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s));
-        else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
+        if (f) {
+            RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, f, w.M, d, s));
+            a.f32 = f; a.A = w.xn; a.W = t->wop(lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
+            RUN(launch_gemm(EPI_BIAS_F16, a, s));
+            RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s));
+        } else {
+            a.A = x; a.W = t->w16 + lw.in_wG; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_bb; a.colsum = F + lw.in_cs; a.rowstat = w.rowstat;
+            a.out = qkv; a.ldc = 3 * d;
+            RUN(launch_gemm(EPI_LNFOLD_F16, a, s));
+            RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
+        }
         a = GemmArgs{};
         a.f32 = f; a.A = att; a.W = t->wop(lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
+        a.stat_part = f ? nullptr : w.stat_part;
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
-        RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, f, w.M, d, s));
         a = GemmArgs{};
-        a.f32 = f; a.A = w.xn; a.W = t->wop(lw.fc_w); a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.h; a.ldc = 4 * d;
+        if (f) {
+            RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, f, w.M, d, s));
+            a.f32 = f; a.A = w.xn; a.W = t->wop(lw.fc_w); a.bias = F + lw.fc_b;
+        } else {
+            RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
+            a.A = x_mid; a.W = t->w16 + lw.fc_wG; a.bias = F + lw.fc_bb; a.colsum = F + lw.fc_cs; a.rowstat = w.rowstat;
+        }
+        a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.out = w.h; a.ldc = 4 * d;
         a.out2 = w.train ? w.hpre_l[(size_t)l] : nullptr;
-        RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
+        RUN(launch_gemm(f ? EPI_BIAS_GELU_F16 : EPI_LNFOLD_GELU_F16, a, s));
         a = GemmArgs{};
         a.f32 = f; a.A = w.h; a.W = t->wop(lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
+        a.stat_part = (f || last) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
+        if (!f && !last) RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
         x = x_out;
     }
     *x_final = x;
@@ -370,7 +413,7 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         a.f32 = f; a.A = w.patches; a.W = t->wop(t->L.conv_w); a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, batch, G2, d, s));
+        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, w.rowstat, batch, G2, d, s));
         resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/0, s, &xf));
         RUN(launch_gather_ln_f16(xf, nullptr, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, batch, d, s));
@@ -396,7 +439,7 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         const int d = D.width, f = t->f32;
         const float* F = t->w32;
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, n_class, w.S, d, D.vocab, s));
+        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, w.rowstat, n_class, w.S, d, D.vocab, s));
         resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/1, s, &xf));
         RUN(launch_gather_ln_f16(xf, eot_index, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, n_class, d, s));
@@ -419,6 +462,20 @@ extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int
     a.aux = aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
     if (variant == 7) { a.f32 = 1; a.variant = 0; }   // f32 operands: the exact-mode kernel (gemm_f32.hip)
     return launch_gemm(epi, a, (hipStream_t)stream);
+}
+extern "C" int grip_debug_gemm_ln(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid, void* out, void* out2,
+                                  float* stat_part, const float* rowstat, const float* colsum, int m_pad, int variant, void* stream) {
+    GemmArgs a{};
+    a.variant = variant;
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid; a.out = out; a.out2 = out2; a.ldc = N;
+    a.stat_part = stat_part; a.rowstat = rowstat; a.colsum = colsum;
+    return launch_gemm(epi, a, (hipStream_t)stream);
+}
+extern "C" int grip_debug_ln_fold(const void* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* colsum, float* bias_out,
+                                  int N, int K, const float* stat_part, int parts, float* rowstat, int M, int d, void* stream) {
+    int rc = launch_ln_fold_weights((const half_t*)W, gamma, beta, bias, (half_t*)Wg, colsum, bias_out, N, K, (hipStream_t)stream);
+    if (rc || !stat_part) return rc;
+    return launch_ln_stats_finalize(stat_part, parts, rowstat, M, d, (hipStream_t)stream);
 }
 extern "C" int grip_debug_attention_exact(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
     return launch_attention_fwd_f32((const float*)qkv, (float*)out, B, S, H, causal, (hipStream_t)stream);

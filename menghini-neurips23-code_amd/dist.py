@@ -45,6 +45,64 @@ def _via_host():
     return dist.get_backend() == "gloo"
 
 
+class NativeComm:
+    """The C ABI's own RCCL communicator (include/grip_amd.h: grip_comm_*, grip_allgather_embeddings, grip_allreduce_mean):
+    what a host that is not PyTorch binds for the two exchange steps.  The ncclUniqueId travels through torch.distributed's
+    object broadcast here (any side channel works).  Opt-in for the Python host (GRIP_NATIVE_COMM=1); the default path
+    below uses torch.distributed's RCCL process group, which is the same library."""
+
+    def __init__(self):
+        import ctypes
+        from . import native
+        self.lib = native.lib()
+        self.rank, self.ws = world()
+        os.environ.setdefault("GRIP_RCCL_LIBRARY", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        ident = (ctypes.c_uint8 * 128)()
+        if self.rank == 0:
+            native.check(self.lib.grip_comm_unique_id(ident))
+        box = [bytes(ident)]
+        if self.ws > 1:
+            dist.broadcast_object_list(box, src=0)
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        h = ctypes.c_void_p()
+        native.check(self.lib.grip_comm_init_rank(buf, self.ws, self.rank, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.grip_comm_destroy(self.handle)
+            self.handle = None
+
+    def allgather(self, local, per):
+        from . import native
+        import ctypes
+        local = local.contiguous()
+        out = torch.empty(self.ws * per, local.shape[1], dtype=torch.float32, device=local.device)
+        native.check(self.lib.grip_allgather_embeddings(self.handle, ctypes.c_void_p(local.data_ptr()), ctypes.c_void_p(out.data_ptr()), per,
+                                                        local.shape[1], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    def allreduce_mean_(self, flat):
+        from . import native
+        import ctypes
+        native.check(self.lib.grip_allreduce_mean(self.handle, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return flat
+
+
+_NATIVE = None
+
+
+def native_comm():
+    """The process-wide NativeComm when GRIP_NATIVE_COMM=1 and the ranks talk RCCL, else None."""
+    global _NATIVE
+    if os.environ.get("GRIP_NATIVE_COMM") != "1" or not is_dist() or _via_host():
+        return None
+    if _NATIVE is None:
+        _NATIVE = NativeComm()
+    return _NATIVE
+
+
 def shard_range(n, rank=None, world_size=None):
     """Contiguous shard [lo, hi) of an ordered pool of n units, equal padded length `per`."""
     if rank is None:
@@ -70,6 +128,9 @@ def allgather_rows(local, n_total, per):
         host = torch.empty(ws * per, e, dtype=local.dtype)
         dist.all_gather_into_tensor(host, local.cpu().contiguous())
         return host[:n_total].to(local.device)
+    nc = native_comm()
+    if nc is not None and local.is_cuda and local.dtype == torch.float32:
+        return nc.allgather(local, per)[:n_total]
     out = torch.empty(ws * per, e, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out[:n_total]
@@ -85,6 +146,9 @@ def allreduce_mean_(tensors):
         h = flat.cpu()
         dist.all_reduce(h)
         flat = h.to(flat.device)
+    elif native_comm() is not None and flat.is_cuda and flat.dtype == torch.float32:
+        native_comm().allreduce_mean_(flat)
+        flat *= ws          # (the C ABI returns the mean; undo so the common tail below applies)
     else:
         dist.all_reduce(flat)
     flat /= ws

@@ -46,11 +46,20 @@ _SIGS = {
     "grip_preprocess_image": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_leaderboard_scan": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
+    "grip_comm_unique_id": (c_int, [c_void_p]),
+    "grip_comm_init_rank": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "grip_comm_destroy": (c_int, [c_void_p]),
+    "grip_allgather_embeddings": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "grip_allreduce_mean": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 EXPORTS = tuple(_SIGS)   # the drop-in ABI (include/grip_amd.h)
 _DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of the ABI
     "grip_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]),
     "grip_debug_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "grip_debug_gemm_ln": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_void_p]),
+    "grip_debug_ln_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                   c_int, c_int, c_void_p]),
     "grip_debug_attention_exact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "grip_profile_enable": (c_int, [c_int]),
     "grip_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),

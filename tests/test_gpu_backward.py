@@ -192,7 +192,7 @@ def _full_size_text_gradient(m, g, tag, dt, cos_tol=1e-3, rel_tol=3e-2):
             tok = ctok.clone()          # a fresh tensor: the cached sequence length lives on the token tensor
             tprefix = _inputs(f"{tag}.tprefix", (1, 16, dt), 0.02).cuda().requires_grad_(True)
             out = TextPrefixFn.apply(tower, tok, tprefix)
-            assert (tok._grip_seq_len < 77) == truncate
+            assert (0 < tok._grip_seq_len < 77) == truncate
             (out ** 2).sum().backward()
             assert_grad_close(tprefix.grad, want, f"{tag} textual prompt grad (truncate={truncate})", cos_tol, rel_tol)
         finally:

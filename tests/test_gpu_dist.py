@@ -84,3 +84,25 @@ def test_bench_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["selected_pairs"] > 0 and "cpu_baseline" not in d
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0
+
+
+def test_native_rccl_communicator_single_rank():
+    """The C ABI's RCCL entry points (grip_comm_*, grip_allgather_embeddings, grip_allreduce_mean) execute on this box's one
+    GPU: a 1-rank communicator is created through RCCL, the all-gather returns the local rows, the mean all-reduce is the
+    identity.  (More than one rank per GPU is refused by RCCL itself; the N > 1 data path is covered over gloo above and its
+    RCCL form is measured by the driver's multi-GPU bench.)"""
+    import grip_amd  # noqa: F401
+    from grip_amd import dist as gdist
+    torch.cuda.set_device(0)
+    c = gdist.NativeComm()
+    try:
+        assert (c.rank, c.ws) == (0, 1)
+        local = torch.randn(37, 512, device="cuda")
+        out = c.allgather(local, 37)
+        g = torch.randn(8192, device="cuda")
+        want = g.clone()
+        c.allreduce_mean_(g)
+        torch.cuda.synchronize()
+        assert torch.equal(out, local) and torch.equal(g, want)
+    finally:
+        c.close()

@@ -144,3 +144,57 @@ def test_cosine_head_matches_torch():
     torch.testing.assert_close(probs, ref.softmax(-1), rtol=1e-3, atol=1e-6)
     assert (am_l.long() == logits.argmax(1)).all()      # first-max-wins arg-max of its own logits: exact
     assert (am_p.long() == probs.argmax(1)).all()
+
+
+@pytest.mark.parametrize("M,d,N2", [(200, 256, 768), (3408, 768, 2304), (66000, 768, 3072), (35000, 1024, 1024), (77 * 21, 512, 1536)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
+def test_layernorm_folded_into_gemm(M, d, N2, variant):
+    """The LayerNorm-free block structure of the f16 towers: (1) the residual GEMM epilogue emits the per-row partial sums of
+    the stream it writes, (2) ln_stats_finalize turns them into (mean, rstd), (3) the consumer GEMM multiplies the RAW stream
+    with gamma-scaled weights and applies rstd (acc - mean colsum) + (W beta + b) [+ QuickGELU] in its epilogue -- against
+    LayerNorm -> Linear computed by torch in fp32 on the same f16-rounded stream."""
+    if variant in (2, 6) and (d % 256 or N2 % 256):
+        pytest.skip("256x256 tile needs N % 256 == 0")
+    if variant in (2, 3, 6) and M < 1024:
+        pytest.skip("large-tile kernels on a tiny problem add nothing")
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(M + d)
+    Mp = (M + 255) // 256 * 256
+    A = torch.randn(Mp, d, device="cuda", generator=g).half()
+    A[M:] = float("nan")
+    W1 = (torch.randn(d, d, device="cuda", generator=g) * d ** -0.5).half()
+    b1 = torch.randn(d, device="cuda", generator=g)
+    resid = (torch.randn(M, d, device="cuda", generator=g) * 2 + 0.7 * torch.randn(M, 1, device="cuda", generator=g) + 0.5).half()
+    # (1) residual epilogue + statistics
+    x = torch.full((Mp, d), float("nan"), device="cuda", dtype=torch.float16)
+    parts = d // 64
+    stat = torch.full((M, parts, 2), float("nan"), device="cuda")
+    native.check(lib.grip_debug_gemm_ln(3, _p(A), _p(W1), M, d, d, _p(b1), _p(resid), _p(x), None, _p(stat), None, None, Mp, variant, _stream()))
+    ref_x32 = A[:M].float() @ W1.float().t() + b1 + resid.float()
+    torch.testing.assert_close(x[:M].float(), ref_x32, rtol=2e-3, atol=2e-3)
+    tiles = ref_x32.reshape(M, parts, 64)
+    torch.testing.assert_close(stat[..., 0], tiles.sum(-1), rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(stat[..., 1], (tiles ** 2).sum(-1), rtol=1e-3, atol=5e-2)
+    # (2) finalize + folded weights
+    W2 = (torch.randn(N2, d, device="cuda", generator=g) * d ** -0.5).half()
+    b2 = torch.randn(N2, device="cuda", generator=g)
+    gamma = 1 + 0.3 * torch.randn(d, device="cuda", generator=g)
+    beta = 0.2 * torch.randn(d, device="cuda", generator=g)
+    Wg = torch.empty_like(W2)
+    cs, bb = torch.empty(N2, device="cuda"), torch.empty(N2, device="cuda")
+    rowstat = torch.empty(Mp, 2, device="cuda")
+    native.check(lib.grip_debug_ln_fold(_p(W2), _p(gamma), _p(beta), _p(b2), _p(Wg), _p(cs), _p(bb), N2, d, _p(stat), parts, _p(rowstat), M, d, _stream()))
+    xs = x[:M].float()
+    torch.testing.assert_close(rowstat[:M, 0], xs.mean(-1), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(rowstat[:M, 1], (xs.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=2e-3, atol=1e-4)
+    torch.testing.assert_close(cs, Wg.float().sum(-1), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bb, b2 + W2.float() @ beta, rtol=1e-4, atol=1e-4)
+    # (3) the folded consumer GEMM against LayerNorm -> Linear in fp32
+    want = torch.nn.functional.layer_norm(xs, (d,), gamma, beta, 1e-5) @ W2.float().t() + b2
+    out = torch.full((M, N2), float("nan"), device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_gemm_ln(7, _p(x), _p(Wg), M, N2, d, _p(bb), None, _p(out), None, None, _p(rowstat), _p(cs), Mp, variant, _stream()))
+    torch.testing.assert_close(out.float(), want, rtol=4e-3, atol=4e-3)
+    pre = torch.full((M, N2), float("nan"), device="cuda", dtype=torch.float16)
+    native.check(lib.grip_debug_gemm_ln(8, _p(x), _p(Wg), M, N2, d, _p(bb), None, _p(out), _p(pre), None, _p(rowstat), _p(cs), Mp, variant, _stream()))
+    torch.testing.assert_close(pre.float(), want, rtol=4e-3, atol=4e-3)
+    torch.testing.assert_close(out.float(), quick_gelu(want), rtol=4e-3, atol=4e-3)

@@ -13,7 +13,7 @@ from grip_amd import clip, engine, pseudolabels as pl  # noqa: E402
 from grip_amd.data.synthetic import pool_paths, structured_images  # noqa: E402
 from oracle import leaderboard as LB  # noqa: E402
 
-fx = np.load(os.path.join(REPO, "tests", "golden", sys.argv[1] if len(sys.argv) > 1 else "exact_vitb16_probs.npz"))
+fx = np.load(os.path.join(REPO, "tests", "golden", sys.argv[1] if len(sys.argv) > 1 else "exact_vitb16_c102.npz"))
 o = fx["probs"]
 n, C = o.shape
 paths = pool_paths(n)
