@@ -79,8 +79,13 @@ __device__ __forceinline__ int slab_off(int row, int chunk) {
     else return row * 64 + ((chunk ^ (row & 15)) * 4);
 }
 
-template <int EPI, int ROWFRAGS, bool CHECK, int PF>
-__device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
+// PRE (persistent kernel, LayerNorm-folded epilogues): the (mean, rstd) pairs of the wave's 128 rows were loaded at the START of
+// the tile -- lane l holds rows l and 64 + l in pre[0] / pre[1] -- and each row group fetches its pair with two ds_bpermute
+// instead of a global load whose latency the first pass of the epilogue cannot hide (that exposure cost the folded QKV /
+// c_fc GEMMs 8 % against their plain-bias forms).
+template <int EPI, int ROWFRAGS, bool CHECK, int PF, bool PRE = false>
+__device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane,
+                                                   const float2* pre = nullptr) {
     constexpr int NP = ROWFRAGS / PF;
     constexpr int RP = 16 * PF;        // rows per pass
     constexpr int NI = 4 * PF;         // row groups (4 rows each) per pass
@@ -114,7 +119,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
             const uint32_t o = elem_off(p, it);
             if constexpr (RESID) res[b][it] = *(const half4*)((const half_t*)g.resid + o);
             if constexpr (EPI == EPI_GELUGRAD_F16) aux[b][it] = *(const half4*)((const half_t*)g.aux + o);
-            if constexpr (FOLD) {
+            if constexpr (FOLD && !PRE) {
                 int row = row0 + p * RP + it * 4 + rr;
                 if constexpr (CHECK) row = row < g.M ? row : g.M - 1;
                 rst[b][it] = ((const float2*)g.rowstat)[row];      // the 16 lanes of a row read one address: a broadcast load
@@ -126,14 +131,14 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
         csum = *(const f32x4*)(g.colsum + col);
         bfold = *(const f32x4*)(g.bias + col);
     }
-    if constexpr (RESID || EPI == EPI_GELUGRAD_F16 || FOLD) prefetch(0, 0);
+    if constexpr (RESID || EPI == EPI_GELUGRAD_F16 || (FOLD && !PRE)) prefetch(0, 0);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int ii = 0; ii < PF; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(f32x4*)(slab + slab_off<PF>(ii * 16 + frow, j * 4 + fgrp)) = acc[PF * p + ii][j];
-        if constexpr (RESID || EPI == EPI_GELUGRAD_F16 || FOLD)
+        if constexpr (RESID || EPI == EPI_GELUGRAD_F16 || (FOLD && !PRE))
             if (p + 1 < NP) prefetch(p + 1, (p + 1) & 1);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -154,6 +159,14 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                         ((float2*)g.stat_part)[(uint32_t)row * (uint32_t)(g.N >> 6) + (uint32_t)(col0 >> 6)] = make_float2(sm, sq);   // M * N / 64 < 2^31
                 }
             }
+            float2 stp = make_float2(0.f, 0.f);
+            if constexpr (FOLD && PRE) {      // cross-lane fetch with every lane active (outside the row guard below)
+                static_assert(!PRE || PF == 1, "preloaded statistics assume 16-row passes");
+                const int src = (((p & 3) * 16 + it * 4 + rr) << 2);       // lane holding row p*16 + it*4 + rr (mod 64), in bytes
+                const float2 pv = pre[p >> 2];
+                stp.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.x)));
+                stp.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.y)));
+            }
             if (!CHECK || row < g.M) {
                 if constexpr (EPI == EPI_F32) {
                     *(f32x4*)((float*)g.out + o) = v;
@@ -167,7 +180,9 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                     if (g.out2) *(half4*)((half_t*)g.out2 + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)quick_gelu(v[0]), (half_t)quick_gelu(v[1]), (half_t)quick_gelu(v[2]), (half_t)quick_gelu(v[3])};
                 } else if constexpr (FOLD) {
-                    const float2 st = rst[p & 1][it];
+                    float2 st;
+                    if constexpr (PRE) st = stp;
+                    else st = rst[p & 1][it];
                     v = (v - csum * st.x) * st.y + bfold;
                     if constexpr (EPI == EPI_LNFOLD_GELU_F16) {
                         if (g.out2) *(half4*)((half_t*)g.out2 + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -185,12 +200,13 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
     }
 }
 
-template <int EPI, int ROWFRAGS, int PF = 2>
-__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane) {
+template <int EPI, int ROWFRAGS, int PF = 2, bool PRE = false>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane,
+                                              const float2* pre = nullptr) {
     if (row0 + ROWFRAGS * 16 <= g.M)
-        epilogue_rows_impl<EPI, ROWFRAGS, false, PF>(g, acc, slab, row0, col0, lane);
+        epilogue_rows_impl<EPI, ROWFRAGS, false, PF, PRE>(g, acc, slab, row0, col0, lane, pre);
     else
-        epilogue_rows_impl<EPI, ROWFRAGS, true, PF>(g, acc, slab, row0, col0, lane);
+        epilogue_rows_impl<EPI, ROWFRAGS, true, PF, PRE>(g, acc, slab, row0, col0, lane, pre);
 }
 
 // WMF = 16-row fragments per wave along M: 4 -> 128x128 block tile, 2 -> 64x128 (small-M problems such as the
@@ -733,6 +749,16 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        // (mean, rstd) of this wave's 128 rows for the LayerNorm-folded epilogues: issued here, a whole K loop ahead of their use
+        float2 pre[2];
+        if constexpr (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int r = m0 + wr * 128 + h * 64 + lane;
+                r = r < g.M ? r : g.M - 1;
+                pre[h] = ((const float2*)g.rowstat)[r];
+            }
+        }
         load_frags(0, par, 0);
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = (par + kt) & 1;
@@ -748,7 +774,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
             mfma_set(1);
             spread();
         }
-        epilogue_rows<EPI, 8, 1>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane);
+        epilogue_rows<EPI, 8, 1, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
         if (!has_next) break;
         par = (par + nk) & 1;
         t = t_next;
