@@ -187,6 +187,21 @@ int grip_leaderboard_scan(const float* probs, const int32_t* pred, const int64_t
                           int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count);
 
 /* ------------------------------------------------------------------------------------------
+ * clip.tokenize's byte-level BPE (host function; the reference tokenises on every CustomTextEncoder.forward,
+ * models/clip_encoders.py:60, and in utils/clip_pseudolabels.py:25).
+ *   grip_bpe_create        merges = the text of the merges table, one "a b" pair per line in rank order (the lines of
+ *                          bpe_simple_vocab_16e6.txt after its header, in the byte-to-unicode alphabet); ids follow openai/CLIP:
+ *                          256 bytes, 256 end-of-word bytes, the merges, <|startoftext|>, <|endoftext|>
+ *   grip_bpe_encode_word   one pre-token (raw UTF-8 bytes of one match of the CLIP pre-tokenisation pattern) -> ids
+ *   grip_bpe_encode_ascii  a cleaned, lower-cased ASCII text: pre-tokenisation (the CLIP pattern restricted to ASCII) + BPE */
+typedef struct grip_bpe grip_bpe;
+int grip_bpe_create(const char* merges, size_t n_bytes, grip_bpe** out);
+int grip_bpe_destroy(grip_bpe* t);
+int grip_bpe_special_ids(const grip_bpe* t, int32_t* sot, int32_t* eot, int32_t* vocab_size);
+int grip_bpe_encode_word(grip_bpe* t, const uint8_t* word, int n, int32_t* ids, int cap, int* n_out);
+int grip_bpe_encode_ascii(grip_bpe* t, const char* text, int n, int32_t* ids, int cap, int* n_out);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-GPU exchange (one process per GPU, RCCL over the xGMI mesh).  The unlabeled pool shards contiguously over the
  * ranks and the per-rank embeddings are all-gathered once per pass; this replaces the accelerator.gather
  * sites of the reference (e.g. methods/semi_supervised_learning/textual_prompt.py:146-147, 285-286) and, for the trainable

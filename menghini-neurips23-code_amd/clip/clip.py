@@ -98,8 +98,13 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
     m = CLIP(d, device, exact=exact)
     path = os.environ.get("CLIP_WEIGHTS")
     if path:
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("state_dict", sd)
+        # an OpenAI checkpoint: TorchScript archive (what OpenAI publishes) or a pickled state_dict; every dimension is
+        # re-derived from the tensor shapes and must agree with the encoder that was asked for
+        sd = _weights.read_checkpoint(path)
+        got = _weights.dims_from_state_dict(sd, name)
+        if got != d:
+            raise RuntimeError(f"$CLIP_WEIGHTS={path} holds {got}, not the requested {d}")
+        _weights.check_state_dict(sd, d)
         PROVENANCE["weights"] = path
     else:
         _warn_once("weights", "clip.load: no $CLIP_WEIGHTS -- using SYNTHETIC seeded random-init weights (accuracies are meaningless)")

@@ -8,6 +8,11 @@ the documented word-hash stand-in to real BPE.  Upstream also runs `ftfy.fix_tex
 here; text that needs mojibake repair will tokenize differently.
 tests/test_tokenizer.py cross-checks this implementation against transformers.CLIPTokenizer on a synthetic
 merges table.
+
+`encode` runs natively when libgrip_amd.so is built (csrc/bpe.cpp behind grip_bpe_* of the C ABI: pre-tokenisation of
+ASCII text and the merge loop in C++, results cached per word; non-ASCII text is pre-tokenised by the Unicode-aware
+pattern here and merged natively per pre-token).  `encode_python` is the literal Python form of the same algorithm; the
+test suite holds the two (and the independent HF implementation) equal.
 """
 import gzip
 import html
@@ -76,6 +81,32 @@ class SimpleTokenizer:
         self.cache = {"<|startoftext|>": "<|startoftext|>", "<|endoftext|>": "<|endoftext|>"}
         self.pat = re.compile(_PAT, re.IGNORECASE)
         self.sot, self.eot = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
+        self._native = self._make_native(merges)
+
+    def _make_native(self, merges):
+        """grip_bpe handle over the same merges table, or None when the library is not built (the tokenizer is host code: it
+        must keep working for vocabulary inspection on a machine without the extension)."""
+        try:
+            import ctypes
+            from .. import native
+            lib = native.lib()
+            blob = "\n".join(f"{a} {b}" for a, b in merges).encode("utf-8")
+            h = ctypes.c_void_p()
+            native.check(lib.grip_bpe_create(blob, len(blob), ctypes.byref(h)))
+            sot, eot, vs = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+            native.check(lib.grip_bpe_special_ids(h, ctypes.byref(sot), ctypes.byref(eot), ctypes.byref(vs)))
+            assert (sot.value, eot.value, vs.value) == (self.sot, self.eot, len(self.encoder))
+            self._lib, self._check, self._buf = lib, native.check, (ctypes.c_int32 * 4096)()
+            return h
+        except Exception:
+            return None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_native", None):
+                self._lib.grip_bpe_destroy(self._native)
+        except Exception:
+            pass
 
     def bpe(self, token):
         if token in self.cache:
@@ -113,6 +144,30 @@ class SimpleTokenizer:
         return out
 
     def encode(self, text):
+        if self._native is None:
+            return self.encode_python(text)
+        import ctypes
+        text = whitespace_clean(basic_clean(text)).lower()
+        n = ctypes.c_int()
+        if text.isascii():
+            raw = text.encode("ascii")
+            if 2 * len(raw) + 8 > len(self._buf):
+                self._buf = (ctypes.c_int32 * (2 * len(raw) + 8))()
+            self._check(self._lib.grip_bpe_encode_ascii(self._native, raw, len(raw), self._buf, len(self._buf), ctypes.byref(n)))
+            return list(self._buf[: n.value])
+        ids = []
+        for token in re.findall(self.pat, text):
+            if token in ("<|startoftext|>", "<|endoftext|>"):
+                ids.append(self.encoder[token])
+                continue
+            raw = token.encode("utf-8")
+            if len(raw) + 8 > len(self._buf):
+                self._buf = (ctypes.c_int32 * (len(raw) + 8))()
+            self._check(self._lib.grip_bpe_encode_word(self._native, raw, len(raw), self._buf, len(self._buf), ctypes.byref(n)))
+            ids.extend(self._buf[: n.value])
+        return ids
+
+    def encode_python(self, text):
         ids = []
         text = whitespace_clean(basic_clean(text)).lower()
         for token in re.findall(self.pat, text):

@@ -26,7 +26,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 // One 16-row query tile against the K / V^T of one (image, head) held in LDS: scores, softmax, P.V, store.
 // qf = the tile's two Q fragments (unscaled); orow = the output row pointer of this lane's query (+ head offset).
 template <int KVC, bool CAUSAL>
-__device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, half8 (&qf)[2], int qrow, int S, half_t* orow, int lane) {
+__device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, half8 (&qf)[2], int qrow, int S, half_t* orow, int lane, bool do_store = true) {
     constexpr float LOG2E = 1.4426950408889634f;
     const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
@@ -80,7 +80,7 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
         }
         osum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf, osum, 0, 0, 0);
     }
-    if (qrow < S) {
+    if (qrow < S && do_store) {
         const float inv = __builtin_amdgcn_rcpf(osum[0]);
         half_t* op = orow + lg * 4;
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __r
 // 176 us launch at 440 x 12 heads, S = 197: no overlap, the two co-resident workgroups move in lock step); this one
 // takes 169 us.  (An 8-wave variant with batched fragment reads, for more registers per wave, was slower: 191 us.)
 template <int KVC, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H, int n_items) {
+__global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H, int n_items, int dbg) {
     constexpr int SP = KVC * 32;
     constexpr int BUF = 2 * SP * 64;                            // halfs per buffer (K rows + V image)
     constexpr int NQ = (2 * KVC + NW - 1) / NW;                 // query tiles per wave
@@ -235,8 +235,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(const half_t* __
     }
     for (int it = 0;; ++it) {
         const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the item's K has landed
-        __syncthreads();                                    // ... everyone's has, V^T is written, and buffer buf^1 is free
+        // This wave's share of the item's K (LDS-DMA) has landed: it was issued BEFORE the item's V loads, and store_v() at the end
+        // of the previous iteration (the prologue for item 0) consumed those V registers -- the compiler's wait for them
+        // covers every older vector-memory operation.  No explicit vmcnt(0) here: it would also drain the output stores the
+        // wave issued a moment ago and expose their write latency once per item (measured: 433 -> see DESIGN.md us per launch).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the V^T image writes (ds_write) of this wave are done
+        __builtin_amdgcn_s_barrier();                       // ... everyone's K has landed, V^T is written, and buffer buf^1 is free
+        asm volatile("" ::: "memory");
         const int next = item + gridDim.x;
         const bool has_next = next < n_items;
         half8 qf[NQ][2];
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(const half_t* __
             if (qt < n_qt) {
                 asm volatile("" ::: "memory");
                 const int qrow = qt * 16 + li;
-                attn_tile<KVC, false>(Ks, Ks + SP * 64, qf[n], qrow, S, out + ((size_t)b * S + qrow) * D + h * 64, lane);
+                attn_tile<KVC, false>(Ks, Ks + SP * 64, qf[n], qrow, S, out + ((size_t)b * S + qrow) * D + h * 64, lane, !(dbg & 1) || item < 64);
             }
         }
         if (!has_next) break;
@@ -281,7 +286,8 @@ static int launch_pipe(const half_t* qkv, half_t* out, int B, int S, int H, hipS
     }
     const int n_items = B * H;
     const int grid = n_items < resident ? n_items : resident;
-    hipLaunchKernelGGL((attn_fwd_pipe_kernel<KVC, NW>), dim3(grid), dim3(NW * 64), lds, s, qkv, out, S, H, n_items);
+    static const int dbg = getenv("GRIP_ATTN_DBG") ? atoi(getenv("GRIP_ATTN_DBG")) : 0;     // developer experiments (bit 0: skip the output stores)
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<KVC, NW>), dim3(grid), dim3(NW * 64), lds, s, qkv, out, S, H, n_items, dbg);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

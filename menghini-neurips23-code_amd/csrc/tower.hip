@@ -330,6 +330,11 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipS
     const float* F = t->w32;
     resid_t* x = x0;
     const int parts = d / 64;
+    // Train-mode forwards (the prompt-tuning batches: a few thousand rows) keep the literal LayerNorm -> GEMM sequence: there the
+    // stream is L2-resident and a LayerNorm launch costs ~5 us, while the statistics-carrying epilogues make the 20-us GEMMs of
+    // those steps 5 % slower (r02: VPT step 3.8 -> 4.0 ms with the fold).  The switch is the MODE, never the batch size: every
+    // inference call computes a row the same way whatever chunk it arrives in (sharded / re-chunked encodes stay bit-identical).
+    const bool fold = !f && !w.train;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
         const bool last = l + 1 == t->D.layers;
@@ -338,11 +343,12 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipS
         resid_t* x_mid = w.train ? w.x_mid[(size_t)l] : x;
         resid_t* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
         GemmArgs a{};
-        if (f) {
+        if (!fold) {
             RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, f, w.M, d, s));
             a.f32 = f; a.A = w.xn; a.W = t->wop(lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_BIAS_F16, a, s));
-            RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s));
+            if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s));
+            else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
         } else {
             a.A = x; a.W = t->w16 + lw.in_wG; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_bb; a.colsum = F + lw.in_cs; a.rowstat = w.rowstat;
             a.out = qkv; a.ldc = 3 * d;
@@ -351,10 +357,10 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipS
         }
         a = GemmArgs{};
         a.f32 = f; a.A = att; a.W = t->wop(lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
-        a.stat_part = f ? nullptr : w.stat_part;
+        a.stat_part = fold ? w.stat_part : nullptr;
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         a = GemmArgs{};
-        if (f) {
+        if (!fold) {
             RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, f, w.M, d, s));
             a.f32 = f; a.A = w.xn; a.W = t->wop(lw.fc_w); a.bias = F + lw.fc_b;
         } else {
@@ -363,12 +369,12 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipS
         }
         a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.out = w.h; a.ldc = 4 * d;
         a.out2 = w.train ? w.hpre_l[(size_t)l] : nullptr;
-        RUN(launch_gemm(f ? EPI_BIAS_GELU_F16 : EPI_LNFOLD_GELU_F16, a, s));
+        RUN(launch_gemm(fold ? EPI_LNFOLD_GELU_F16 : EPI_BIAS_GELU_F16, a, s));
         a = GemmArgs{};
         a.f32 = f; a.A = w.h; a.W = t->wop(lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
-        a.stat_part = (f || last) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
+        a.stat_part = (!fold || last) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
-        if (!f && !last) RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
+        if (fold && !last) RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
         x = x_out;
     }
     *x_final = x;
@@ -413,7 +419,7 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         a.f32 = f; a.A = w.patches; a.W = t->wop(t->L.conv_w); a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, w.rowstat, batch, G2, d, s));
+        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, train ? nullptr : w.rowstat, batch, G2, d, s));
         resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/0, s, &xf));
         RUN(launch_gather_ln_f16(xf, nullptr, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, batch, d, s));
@@ -439,7 +445,7 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         const int d = D.width, f = t->f32;
         const float* F = t->w32;
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, w.rowstat, n_class, w.S, d, D.vocab, s));
+        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, train ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s));
         resid_t* xf = nullptr;
         RUN(run_blocks(t, w, x0, /*causal=*/1, s, &xf));
         RUN(launch_gather_ln_f16(xf, eot_index, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, n_class, d, s));

@@ -46,6 +46,11 @@ _SIGS = {
     "grip_preprocess_image": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_leaderboard_scan": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
+    "grip_bpe_create": (c_int, [ctypes.c_char_p, c_size_t, POINTER(c_void_p)]),
+    "grip_bpe_destroy": (c_int, [c_void_p]),
+    "grip_bpe_special_ids": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "grip_bpe_encode_word": (c_int, [c_void_p, ctypes.c_char_p, c_int, c_void_p, c_int, POINTER(c_int)]),
+    "grip_bpe_encode_ascii": (c_int, [c_void_p, ctypes.c_char_p, c_int, c_void_p, c_int, POINTER(c_int)]),
     "grip_comm_unique_id": (c_int, [c_void_p]),
     "grip_comm_init_rank": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "grip_comm_destroy": (c_int, [c_void_p]),

@@ -128,3 +128,51 @@ def init_upt_mixer(coop_dim: int, vpt_dim: int, tdim: int = 128, seed: int = 0):
             a = rng.normal(seed, sid, shape, 0.0, {"attn": tdim ** -0.5, "proj": tdim ** -0.5 * 2 ** -0.5, "fc": (2 * tdim) ** -0.5}[kind])
         out[key] = a
     return out
+
+
+# ---------------------------------------------------------------------------------------------- OpenAI checkpoints
+# clip.load of the published openai/CLIP reads `ViT-B-16.pt` etc. as TorchScript archives (torch.jit.load) and falls back to a
+# plain torch.load state_dict; build_model then infers every dimension from the tensor shapes and drops three scalar
+# book-keeping entries.  The reference reaches all of that through clip.load(VIS_ENCODER, device) (methods/clip_baseline.py:39-41).
+NON_WEIGHT_KEYS = ("input_resolution", "context_length", "vocab_size")
+
+
+def read_checkpoint(path):
+    """state_dict (key -> tensor, on the CPU) of an OpenAI CLIP checkpoint: a TorchScript archive (the files OpenAI publishes),
+    a pickled state_dict, or a {"state_dict": ...} wrapper.  f16 tensors stay f16 here; the towers convert on load."""
+    import torch
+    try:
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
+    except Exception:
+        sd = torch.load(path, map_location="cpu")
+        if hasattr(sd, "state_dict") and not isinstance(sd, dict):
+            sd = sd.state_dict()
+        sd = sd.get("state_dict", sd)
+    return {k: v for k, v in sd.items() if k not in NON_WEIGHT_KEYS and not k.endswith("attn_mask")}
+
+
+def dims_from_state_dict(sd, name="checkpoint") -> ClipDims:
+    """Every dimension of a ViT CLIP from its tensor shapes (the inference of the published build_model): width and patch from
+    conv1, layers from the resblock keys, resolution from the positional embedding, heads = width / 64."""
+    if "visual.proj" not in sd:
+        raise RuntimeError("not a ViT CLIP state_dict (ModifiedResNet towers are not supported: the reference only names ViT encoders)")
+    vw, _, p, _ = sd["visual.conv1.weight"].shape
+    vl = len({k.split(".")[3] for k in sd if k.startswith("visual.transformer.resblocks.") and k.endswith(".attn.in_proj_weight")})
+    grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    tw = sd["ln_final.weight"].shape[0]
+    tl = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks.") and k.endswith(".attn.in_proj_weight")})
+    return ClipDims(name, sd["text_projection"].shape[1], grid * p, vl, vw, p, sd["positional_embedding"].shape[0], sd["token_embedding.weight"].shape[0],
+                    tw, tw // 64, tl)
+
+
+def check_state_dict(sd, d: ClipDims):
+    """Raises with a precise message when `sd` is not a complete set of weights for dims `d` (missing / unexpected keys, shapes)."""
+    spec = {k: tuple(s) for k, s, _ in weight_spec(d)}
+    missing = [k for k in spec if k not in sd]
+    extra = [k for k in sd if k not in spec]
+    if missing or extra:
+        raise RuntimeError(f"state_dict does not match {d.name}: missing {missing[:4]}{'...' if len(missing) > 4 else ''}, "
+                           f"unexpected {extra[:4]}{'...' if len(extra) > 4 else ''}")
+    for k, shape in spec.items():
+        if tuple(sd[k].shape) != shape:
+            raise RuntimeError(f"state_dict does not match {d.name}: {k} has shape {tuple(sd[k].shape)}, expected {shape}")

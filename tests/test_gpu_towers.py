@@ -173,3 +173,29 @@ def test_text_truncation_at_the_longest_eot_is_exact(models):
         grads.append(p.grad.clone())
     tt.truncate_text_at_eot = True
     torch.testing.assert_close(grads[0], grads[1], rtol=1e-4, atol=1e-6)
+
+
+def test_clip_load_from_a_torchscript_archive(tmp_path, monkeypatch, models):
+    """$CLIP_WEIGHTS pointing at a TorchScript archive of the OpenAI form: clip.load reads it with torch.jit.load,
+    re-derives the dimensions from the shapes, refuses a mismatching encoder name, and the towers reproduce the embeddings
+    of the directly initialised model (GEMM operands are rounded to f16 in either path)."""
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, config, weights
+    from test_checkpoint_loader import _Scriptable, _module_tree
+    d = config.get_dims("small")
+    sd = {k: torch.from_numpy(v).half() if v.ndim >= 2 else torch.from_numpy(v) for k, v in weights.init_state_dict(d, 0).items()}
+    path = str(tmp_path / "small.pt")
+    torch.jit.save(torch.jit.script(_Scriptable(_module_tree(sd), {"input_resolution": 64, "context_length": 77, "vocab_size": d.vocab_size})), path)
+    monkeypatch.setenv("CLIP_WEIGHTS", path)
+    m, _ = clip.load("small", device="cuda")
+    assert clip.clip.PROVENANCE["weights"] == path
+    x = _inputs("ts.x", (3, 3, 64, 64)).cuda()
+    tok = torch.zeros(2, 77, dtype=torch.int32)
+    tok[:, 0], tok[0, 1:4], tok[1, 1:3] = 49406, torch.tensor([1000, 2000, 49407]), torch.tensor([3000, 49407])
+    ref = models("small")
+    assert_embeddings_close(m.encode_image(x), ref.encode_image(x).cpu(), "archive vs direct: image")
+    assert_embeddings_close(m.encode_text(tok.cuda()), ref.encode_text(tok.cuda()).cpu(), "archive vs direct: text")
+    with pytest.raises(RuntimeError, match="not the requested"):
+        clip.load("tiny", device="cuda")
+    with pytest.raises(RuntimeError, match="no BPE vocabulary"):        # real weights + the stand-in tokenizer would be garbage (ADVICE r1)
+        clip.tokenize(["a photo of a forest"])

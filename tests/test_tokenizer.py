@@ -56,9 +56,11 @@ def test_bpe_matches_transformers_clip_tokenizer(merges):
     hf = transformers.CLIPTokenizer(vocab=dict(tk.encoder), merges=[tuple(m) for m in merges])
     texts = ["a photo of a forest", "X X X X annual crop land", "a photo of a {}sea lake", "It's the dog's  texture!!",
              "737-800, an airplane", "crosshatched   cobwebbed\tcracked", "unseenword zzz qqq", ""]
+    assert tk._native is not None, "libgrip_amd.so is built in this tree: the native BPE must be the one behind encode()"
     for t in texts:
         want = hf(t, add_special_tokens=False)["input_ids"]
-        assert tk.encode(t) == want, (t, tk.encode(t), want)
+        assert tk.encode(t) == want, (t, tk.encode(t), want)               # native (csrc/bpe.cpp)
+        assert tk.encode_python(t) == want, (t, tk.encode_python(t), want)   # literal Python form
     ids = tk.encode("a photo of a river")
     assert tk.decode(ids).strip() == "a photo of a river"
 
@@ -84,3 +86,23 @@ def test_tokenize_switches_to_bpe_when_a_vocab_file_is_supplied(merges, tmp_path
     monkeypatch.setattr(gclip, "_TOKENIZER", None)          # leave the module in its default (stand-in) state
     monkeypatch.delenv("CLIP_BPE_VOCAB")
     assert gclip.tokenize(["x"])[0, 1].item() == 343
+
+
+def test_native_bpe_equals_python_bpe_on_edge_cases(merges):
+    """csrc/bpe.cpp against the literal Python algorithm: contractions and their priority over punctuation runs, digits one
+    at a time, special tokens inside text, html entities, tabs / newlines, non-ASCII text (Unicode-aware pre-tokenisation on
+    the host + native merges per pre-token), very long words, empty input, repeated calls (the per-word cache)."""
+    import random
+
+    import grip_amd  # noqa: F401
+    from grip_amd.clip.simple_tokenizer import SimpleTokenizer
+    tk = SimpleTokenizer(merges=merges)
+    assert tk._native is not None
+    texts = ["", " ", "it's we're they'll i'd you've i'm don't", "!!'s ''t 'x '", "a1b22c333 737-800", "<|startoftext|>a photo<|endoftext|> of",
+             "forest&amp;river &lt;tag&gt;", "tab\tnew\nline\r\n  end", "caf\u00e9 na\u00efve \u00fcber stra\u00dfe", "\u6f22\u5b57 kanji \u0440\u0435\u043a\u0430 river",
+             "x" * 300, "A PHOTO OF A FOREST", "semi;colon:colon,comma.dot", "forest forest forest river forest"]
+    rnd = random.Random(3)
+    alphabet = "abcdefghijklmnopqrstuvwxyz  0123456789'-.,!?"
+    texts += ["".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 60))) for _ in range(200)]
+    for t in texts + texts[:20]:
+        assert tk.encode(t) == tk.encode_python(t), repr(t)
