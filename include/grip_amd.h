@@ -172,6 +172,26 @@ int grip_preprocess_image(const uint8_t* img, int H, int W,
                           int crop_left, int crop_top, int n_px, const float* mean3, const float* std3,
                           uint8_t* tmp, float* out, void* stream);
 
+/* The same for a whole batch of decoded images of different sizes in ONE launch pair (the host decodes JPEGs on a thread pool and
+ * uploads the batch as one packed buffer).  `items_device` is a DEVICE array of n_items descriptors; every pointer inside is a
+ * device pointer; hksize = vksize = 0 marks an image that already has the resized size.  max_H = the largest H of the batch.
+ * mean3 / std3: HOST pointers to 3 floats. */
+typedef struct {
+    const uint8_t* img;        /* [H, W, 3] u8 */
+    int32_t H, W;
+    const int32_t* hcoef;      /* [W_out, hksize] */
+    const int32_t* hbounds;    /* [W_out, 2] */
+    int32_t hksize, W_out;
+    const int32_t* vcoef;      /* [H_out, vksize] */
+    const int32_t* vbounds;    /* [H_out, 2] */
+    int32_t vksize, H_out;
+    int32_t crop_left, crop_top;
+    uint8_t* tmp;              /* [H, n_px, 3] u8 scratch */
+    float* out;                /* [3, n_px, n_px] f32 */
+} grip_preprocess_item;
+int grip_preprocess_batch(const grip_preprocess_item* items_device, int n_items, int max_H, int n_px,
+                          const float* mean3, const float* std3, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Sequential per-class leaderboard: utils/clip_pseudolabels.py:49-112 and the nine
  * assign_pseudo_labels (e.g. methods/transductive_zsl/multimodal_fpl.py:194-285).  Host function,

@@ -27,6 +27,13 @@ class Slot(ctypes.Structure):
                 ("rows", c_int64), ("cols", c_int64), ("ld", c_int64)]
 
 
+class PreprocessItem(ctypes.Structure):
+    """grip_preprocess_item (include/grip_amd.h); 88 bytes, natural alignment."""
+    _fields_ = [("img", c_void_p), ("H", c_int32), ("W", c_int32), ("hcoef", c_void_p), ("hbounds", c_void_p), ("hksize", c_int32), ("W_out", c_int32),
+                ("vcoef", c_void_p), ("vbounds", c_void_p), ("vksize", c_int32), ("H_out", c_int32), ("crop_left", c_int32), ("crop_top", c_int32),
+                ("tmp", c_void_p), ("out", c_void_p)]
+
+
 _SIGS = {
     "grip_last_error": (ctypes.c_char_p, []),
     "grip_abi_version": (c_int, []),
@@ -45,6 +52,7 @@ _SIGS = {
     "grip_weighted_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "grip_preprocess_image": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "grip_preprocess_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "grip_leaderboard_scan": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
     "grip_bpe_create": (c_int, [ctypes.c_char_p, c_size_t, POINTER(c_void_p)]),
     "grip_bpe_destroy": (c_int, [c_void_p]),

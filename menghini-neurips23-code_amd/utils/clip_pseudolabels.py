@@ -15,7 +15,8 @@ log = logging.getLogger(__name__)
 def _pool_images(dataset, transform, device):
     """Images of `dataset.filepaths` in order.  A dataset may carry a pre-decoded tensor pool as
     `dataset.images` ([N,3,R,R], aligned with filepaths); otherwise files are opened with PIL and
-    `transform` is applied per image (host I/O, as the reference does; batched on the device after)."""
+    decoded on a thread pool and preprocessed in one batched launch per chunk (`transform.load_batch` of the native
+    ClipPreprocess; a foreign transform is applied per image as the reference does)."""
     images = getattr(dataset, "images", None)
     if images is not None:
         return images
@@ -25,6 +26,8 @@ def _pool_images(dataset, transform, device):
         n = len(dataset.filepaths)
 
         def __call__(self, lo, hi):
+            if hasattr(transform, "load_batch"):      # the native preprocess of clip.load: thread-pool decode + one batched launch
+                return transform.load_batch(dataset.filepaths[lo:hi])
             return torch.stack([transform(Image.open(p).convert("RGB")) for p in dataset.filepaths[lo:hi]])
     return _Lazy()
 

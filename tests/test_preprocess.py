@@ -92,3 +92,62 @@ def test_clip_load_returns_the_gpu_preprocess_and_it_feeds_the_encoder():
     assert torch.isfinite(m.encode_image(x)).all()
     t = torch.randn(3, 64, 64)
     assert preprocess(t) is t                                      # already-preprocessed tensors pass through
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_px", [224, 32])
+def test_batched_preprocess_equals_per_image_and_pil(n_px, tmp_path):
+    """grip_preprocess_batch (one packed upload + one launch pair for images of mixed sizes, incl. one that needs no resize) is
+    bit-identical to the per-image kernels, hence to PIL's transform; load_batch decodes files on a thread pool first."""
+    import grip_amd  # noqa: F401
+    from grip_amd.preprocess import ClipPreprocess
+    pre = ClipPreprocess(n_px, "cuda")
+    sizes = SIZES + [(n_px, n_px), (n_px, 2 * n_px), (333, 77)]
+    arrs = [_img(h, w, 3 * h + w) for h, w in sizes]
+    single = torch.stack([pre(torch.from_numpy(a)) for a in arrs])
+    batch = pre.batch([Image.fromarray(a) if i % 2 else a for i, a in enumerate(arrs)])
+    assert batch.shape == (len(arrs), 3, n_px, n_px) and torch.equal(batch, single)
+    for a, b in zip(arrs[:4], batch[:4]):
+        np.testing.assert_allclose(b.cpu().numpy(), _reference_transform(a, n_px), rtol=0, atol=2e-6)
+    paths = []
+    for i, a in enumerate(arrs):
+        p = tmp_path / f"im{i}.png"                 # lossless: the decoded pixels are exactly `a`
+        Image.fromarray(a).save(p)
+        paths.append(str(p))
+    for workers in (1, 4):
+        assert torch.equal(pre.load_batch(paths, workers=workers), single)
+    assert pre.batch([]).shape == (0, 3, n_px, n_px)
+
+
+@pytest.mark.gpu
+def test_pseudolabel_pool_from_image_files_uses_the_batched_loader(tmp_path, monkeypatch):
+    """utils.pseudolabel_top_k on a dataset of image FILES (no pre-decoded pool): files are decoded on the thread pool and
+    preprocessed by the batched kernel chunk by chunk; same lists as with the images preprocessed one by one up front."""
+    import types
+
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    from grip_amd.utils import pseudolabel_top_k
+    monkeypatch.chdir(tmp_path)
+    m, preprocess = clip.load("small", device="cuda")
+    g = np.random.RandomState(5)
+    paths = []
+    for i in range(23):
+        a = np.clip(g.normal(128 + 40 * g.randn(3), 50, size=(70 + i, 90 - i, 3)), 0, 255).astype(np.uint8)
+        p = tmp_path / f"{i:03d}.png"
+        Image.fromarray(a).save(p)
+        paths.append(str(p))
+    classes = ["forest", "river", "highway"]
+    l2i = {c: i for i, c in enumerate(classes)}
+    cfg = types.SimpleNamespace(LEARNING_PARADIGM="ul", MODEL="textual_fpl")
+
+    class DS:
+        def __init__(self, images=None):
+            self.filepaths, self.labels = list(paths), None
+            if images is not None:
+                self.images = images
+    files = DS()
+    pseudolabel_top_k(cfg, "Files", 3, "a photo of a {}", files, classes, preprocess, m, l2i, "cuda", "small", 1)
+    pool = DS(torch.stack([preprocess(Image.open(p)) for p in paths]))
+    pseudolabel_top_k(cfg, "Pool", 3, "a photo of a {}", pool, classes, preprocess, m, l2i, "cuda", "small", 1)
+    assert (files.filepaths, files.labels) == (pool.filepaths, pool.labels) and len(files.filepaths) > 3
