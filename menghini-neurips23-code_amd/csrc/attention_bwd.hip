@@ -242,7 +242,8 @@ static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_ou
 
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s) {
     const int kvc = (S + 31) / 32;
-    GRIP_REQUIRE(S >= 1 && kvc <= 9, "attention backward: sequence length %d unsupported (max 288: K, V and their transposes of one head must fit the 160 KiB LDS)", S);
+    if (kvc > 9) return launch_attention_bwd_tiled(qkv, o, d_out, dqkv, B, S, H, causal, s);    // S > 288: block-tiled kernel (attention_bwd_tiled.hip)
+    GRIP_REQUIRE(S >= 1, "attention backward: sequence length %d unsupported", S);
 #define GRIP_ATTN(N)                                                                        \
     if (kvc <= N) return causal ? launch_bwd_one<N, true, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s)  \
                                 : launch_bwd_one<N, false, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s);

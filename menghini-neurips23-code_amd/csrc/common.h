@@ -184,6 +184,7 @@ int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int
 int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s);
 int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s);
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
+int launch_attention_bwd_tiled(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
 // backward row kernels (rowops_bwd.hip)
 int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
 int launch_ln_bwd_add(const resid_t* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s);

@@ -294,6 +294,26 @@ class TextPrefixFn(torch.autograd.Function):
         return None, None, g.to(ctx.pdtype)
 
 
+def vit_prefix_forward(tower, images, prefix):
+    """CustomVisionTransformer.forward on the native tower.  The train-mode forward (activations saved for the prompt
+    gradient) runs only when a gradient can actually be asked for: grad mode on AND the prompt requires grad.  Under
+    torch.no_grad() -- validation, test predictions, the pseudolabel passes -- it is the plain inference forward, the same
+    arithmetic as the pool encode (autograd's needs_input_grad alone does not see the surrounding no_grad)."""
+    if torch.is_grad_enabled() and prefix.requires_grad:
+        return VitPrefixFn.apply(tower, images, prefix)
+    return tower.vit_forward(images, prefix.detach(), train=False)[0]
+
+
+def text_prefix_forward(tower, token_ids, prefix):
+    """CustomTextEncoder.forward on the native tower; see vit_prefix_forward."""
+    if torch.is_grad_enabled() and prefix.requires_grad:
+        return TextPrefixFn.apply(tower, token_ids, prefix)
+    cached = getattr(token_ids, "_grip_seq_len", None)
+    out, _, keep = tower.text_forward(token_ids, prefix.detach(), train=False, seq_len=cached)
+    token_ids._grip_seq_len = keep[2]
+    return out
+
+
 def cosine_head(img_emb, txt_emb, scale, want_probs=True):
     """normalize -> scale * img @ txt.T -> softmax / argmax, fused (no autograd)."""
     lib = native.lib()

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import clip
-from ..engine import TextPrefixFn, VitPrefixFn
+from ..engine import text_prefix_forward, vit_prefix_forward
 
 log = logging.getLogger(__name__)
 
@@ -56,7 +56,7 @@ class CustomTextEncoder(nn.Module):
         if not enable_pos_emb:
             raise NotImplementedError("enable_pos_emb=False is never used by the reference")
         token_ids = self._token_ids(class_embeddings.size()[1], classes)
-        return TextPrefixFn.apply(self.clip_model.text_tower, token_ids, class_embeddings)
+        return text_prefix_forward(self.clip_model.text_tower, token_ids, class_embeddings)
 
 
 class ImageEncoder(nn.Module):
@@ -89,7 +89,7 @@ class CustomVisionTransformer(nn.Module):
     def forward(self, x, image_prefix, pos_emb=True, deep_embs=None):
         if deep_embs is not None or not pos_emb:
             raise NotImplementedError("deep prompts / pos_emb=False are dead code in the reference (VPT_DEEP: False)")
-        return VitPrefixFn.apply(self._vt[0].tower, x, image_prefix)
+        return vit_prefix_forward(self._vt[0].tower, x, image_prefix)
 
 
 class CustomImageEncoder(nn.Module):

@@ -37,7 +37,10 @@ def assert_grad_close(got, want, what, cos_tol=1e-3, rel_tol=3e-2):
     assert rel <= rel_tol, f"{what}: relative L2 error {rel:.3e}"
 
 
-@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (2, 40, 2, 1), (2, 77, 8, 1), (2, 197, 12, 0), (1, 213, 12, 0), (1, 250, 3, 0), (1, 273, 4, 0), (2, 120, 2, 0), (1, 150, 2, 1)])
+@pytest.mark.parametrize("B,S,H,causal", [(2, 17, 2, 0), (2, 40, 2, 1), (2, 77, 8, 1), (2, 197, 12, 0), (1, 213, 12, 0), (1, 250, 3, 0), (1, 273, 4, 0), (2, 120, 2, 0), (1, 150, 2, 1),
+                                          # S > 288: the block-tiled kernel (attention_bwd_tiled.hip); 577 / 581 / 593 = ViT-L/14@336px without / with 4 / 16 prompt tokens
+                                          (1, 289, 2, 0), (2, 300, 3, 0), (1, 448, 2, 0), (1, 449, 1, 0), (2, 577, 16, 0), (1, 581, 4, 0), (1, 593, 16, 0), (1, 608, 2, 0),
+                                          (1, 320, 2, 1), (1, 500, 1, 1)])
 def test_attention_backward(B, S, H, causal):
     import grip_amd  # noqa: F401
     from grip_amd import native
@@ -246,3 +249,18 @@ def test_golden_vitl14_336_text_gradient(models, golden_vitl14):
     """BASELINE.json configs[4] (FGVCAircraft GRIP textual, ViT-L/14@336px): CoOp prompt gradient through the 12-head, 768-wide
     text tower at its real dimensions."""
     _full_size_text_gradient(models("ViT-L/14@336px"), golden_vitl14, "g5", 768)
+
+
+def test_golden_vitl14_336_visual_prompt_gradient(models, golden_vitl14):
+    """VERDICT r1 missing #3: a visual prompt on ViT-L/14@336px (S = 593 > 288: the block-tiled attention backward) -- gradient
+    of sum(out^2) w.r.t. the 16 prompt tokens through all 24 layers against autograd through the reference's wrappers."""
+    import grip_amd  # noqa: F401
+    from grip_amd.models import CustomImageEncoder, ImagePrefixModel
+    m, g = models("ViT-L/14@336px"), golden_vitl14
+    x = _inputs("g5.x", (2, 3, 336, 336)).cuda()
+    model = ImagePrefixModel(_inputs("g5.vprefix", (16, 1024), 0.02).cuda(), CustomImageEncoder(m.visual), device="cuda")
+    out = model(x)
+    from test_gpu_towers import assert_embeddings_close
+    assert_embeddings_close(out, g["g5.vision_p16"], "L/14@336 vision+prefix (train-mode forward)")
+    (out ** 2).sum().backward()
+    assert_grad_close(model.prefix.grad, g["g5.vision_p16_grad_prefix"], "L/14@336 visual prompt grad")
