@@ -93,6 +93,7 @@ class Loop:
         enc._tok_cache[(self.P, tuple(self.classes))] = self.coop_tokens   # no tokenizer needed
         self.model = TextPrefixModel(prefix, enc, self.classes, device=device)
         self.opt = torch.optim.SGD([self.model.prefix], lr=0.1, weight_decay=0.1)
+        self.graphed = steps.GraphedCoopStep(self.model, self.m, self.opt) if args.graph else None
         self.t_pl = self.t_tr = 0.0
         self.m_selected = 0
         self.train_steps = 0
@@ -132,7 +133,10 @@ class Loop:
             else:   # no selected image lives in this rank's shard: same work, zero weight (it still joins the all-reduce)
                 x, y = self.pool[: a.batch], torch.zeros(a.batch, dtype=torch.int32, device=self.device)
                 w = torch.zeros(a.batch, device=self.device)
-            steps.coop_step(self.model, self.m, x, y, w, self.opt)
+            if self.graphed is not None:
+                self.graphed(x, y, w)
+            else:
+                steps.coop_step(self.model, self.m, x, y, w, self.opt)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         self.t_pl += t1 - t0
@@ -354,6 +358,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64, help="images of the R-mode CPU baseline (BASELINE.md section 3: >= 64)")
     ap.add_argument("--cpu-text-reps", type=int, default=6, help="how many of them time the full clip_model(image, text) call (the per-image text re-encode)")
     ap.add_argument("--cpu-full", action="store_true", help="time the literal R-mode loop on every sampled image (~6 s each)")
+    ap.add_argument("--graph", type=int, default=1, choices=(0, 1),
+                    help="1: the CoOp step's forward + backward replayed from a HIP graph captured once (steps.GraphedCoopStep); 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the fp32 comparison-mode block")
     ap.add_argument("--exact-chunk", type=int, default=220)
@@ -423,7 +429,7 @@ def main():
                    "pool_images_per_gpu": args.pool, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
                    "encode_chunk": args.chunk, "encode_streams": args.streams, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
                    "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps),
-                   "text_positions_encoded": seq,
+                   "text_positions_encoded": seq, "prompt_step_hip_graph": bool(args.graph),
                    "train_sharding": "each rank steps on the selected images of its OWN shard (zero-weight rows where it owns none), batch 16 per rank; "
                                      "prompt gradients are mean-all-reduced every step -- not one global batch split over ranks",
                    "collectives": "RCCL all_gather_into_tensor of [pool, 512] f32 embeddings per pass + all_reduce of the 32 KB prompt gradient per step"

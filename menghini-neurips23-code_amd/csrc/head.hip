@@ -25,12 +25,16 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
 #define HEAD_MAX_EV 8  // e <= 64 * 4 * 8 = 2048
 #define HEAD_MAX_CV 16 // c <= 1024
 
+// One workgroup (4 waves) per image row: the row is normalised and pre-multiplied by the scale in every wave's registers, wave w
+// takes the classes j = w (mod 4) in groups of four (independent row loads and wave reductions in flight), the logits meet in
+// LDS, and wave 0 does the softmax / arg-max tail.  (Round 1 gave a whole row to ONE wave: 102 dependent class trips = 85 us
+// for a 16-row training batch, on the critical path between the text tower's forward and backward.)
 __global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restrict__ img, const float* __restrict__ txtn, float scale,
                                                           int n, int c, int e, float* __restrict__ logits, float* __restrict__ probs,
                                                           int32_t* __restrict__ am_logits, int32_t* __restrict__ am_probs) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    __shared__ float lgs[64 * HEAD_MAX_CV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x;
     const int e4 = e >> 2;
     const f32x4* x = (const f32x4*)(img + (size_t)row * e);
     f32x4 v[HEAD_MAX_EV];
@@ -46,10 +50,7 @@ __global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restric
     for (int i = 0; i < HEAD_MAX_EV; ++i)
         if (lane + 64 * i < e4) v[i] = scale * (v[i] / nrm);
 
-    float lg[HEAD_MAX_CV];  // lane l keeps classes l, l+64, ...
-    // Four classes per trip: their row loads and wave reductions are independent, so a wave that is alone on its SIMD (a
-    // training batch is 16 rows = 16 waves) overlaps four L2 round trips and four shuffle trees instead of one.
-    for (int j0 = 0; j0 < c; j0 += 4) {
+    for (int j0 = wave * 4; j0 < c; j0 += 16) {
         float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -64,14 +65,11 @@ __global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restric
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) d[u] = wsum(d[u]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-#pragma unroll
-            for (int s = 0; s < HEAD_MAX_CV; ++s)
-                if (j < c && (j >> 6) == s && (j & 63) == lane) lg[s] = d[u];
-        }
+        if (lane < 4 && j0 + lane < c) lgs[j0 + lane] = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
     }
+    __syncthreads();
+    if (wave != 0) return;
+    float lg[HEAD_MAX_CV];  // lane l keeps classes l, l+64, ...
     // row max + first arg-max over logits
     float m = -INFINITY;
     int am = 0x7fffffff;
@@ -79,6 +77,7 @@ __global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restric
     for (int s = 0; s < HEAD_MAX_CV; ++s) {
         const int j = s * 64 + lane;
         if (j < c) {
+            lg[s] = lgs[j];
             logits[(size_t)row * c + j] = lg[s];
             if (lg[s] > m) { m = lg[s]; am = j; }
         }
@@ -123,7 +122,7 @@ extern "C" int grip_cosine_head(const float* img_emb, const float* txt_emb, floa
     GRIP_REQUIRE(n > 0 && c > 0 && c <= 64 * HEAD_MAX_CV && e % 4 == 0 && e <= 256 * HEAD_MAX_EV, "cosine_head: unsupported shape n=%d c=%d e=%d", n, c, e);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((c + 3) / 4), dim3(256), 0, s, txt_emb, txt_norm_scratch, c, e);
-    hipLaunchKernelGGL(cosine_head_kernel, dim3((n + 3) / 4), dim3(256), 0, s, img_emb, txt_norm_scratch, scale, n, c, e, logits, probs, argmax_logits, argmax_probs);
+    hipLaunchKernelGGL(cosine_head_kernel, dim3(n), dim3(256), 0, s, img_emb, txt_norm_scratch, scale, n, c, e, logits, probs, argmax_logits, argmax_probs);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

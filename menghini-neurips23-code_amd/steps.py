@@ -80,3 +80,68 @@ def upt_step(model, logit_scale, images, labels, row_weight, optimizer):
     logits = CosineHeadFn.apply(image_features, text_features, logit_scale)
     loss = WeightedCEFn.apply(logits, labels, row_weight)
     return _finish(loss, [p for p in model.parameters() if p.requires_grad], optimizer)
+
+
+class GraphedCoopStep:
+    """coop_step with its forward + backward captured ONCE in a HIP graph and replayed per step (shapes are static within an
+    epoch: same batch size, same class list).  The CoOp step is ~330 launches of 10-25 us on two streams; replaying them
+    as one graph removes the per-launch host cost and the launch gaps, nothing else changes: the captured kernels are the
+    ones coop_step launches, the prompt-gradient all-reduce and the optimizer step stay outside the graph (eager), so the
+    same object serves one GPU and N.  A batch of another size falls back to the eager step.
+
+    Static inputs: images [B,3,R,R] / labels [B] / row weights [B] are copied into fixed buffers before each replay; the
+    prompt parameter is read in place, its .grad is written in place."""
+
+    def __init__(self, model, clip_model, optimizer):
+        self.model, self.clip_model, self.optimizer = model, clip_model, optimizer
+        self.scale = clip_model.logit_scale.exp().item()
+        self.graph = None
+        self.key = None
+
+    def _body(self):
+        side = _side_stream(self.x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            image_features = self.clip_model.encode_image(self.x)
+        text_features = self.model(self.model.classes)
+        torch.cuda.current_stream().wait_stream(side)
+        logits = CosineHeadFn.apply(image_features, text_features, self.scale)
+        loss = WeightedCEFn.apply(logits, self.y, self.w)
+        loss.backward()
+        return loss.detach()
+
+    def _capture(self, images, labels, row_weight):
+        dev = images.device
+        self.x, self.y, self.w = images.clone(), labels.to(torch.int32).clone(), row_weight.to(torch.float32).clone()
+        self.key = (tuple(images.shape), images.dtype, tuple(self.model.classes))
+        prefix = self.model.prefix
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):              # warm-up off the default stream: workspaces, lazy kernel attributes, cached token ids
+            for _ in range(2):
+                prefix.grad = None
+                self._body()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        prefix.grad = torch.zeros_like(prefix)     # the captured backward accumulates into this buffer
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            prefix.grad.zero_()
+            self.loss = self._body()
+        self.grad = prefix.grad
+
+    def __call__(self, images, labels, row_weight):
+        key = (tuple(images.shape), images.dtype, tuple(self.model.classes))
+        if self.graph is None:
+            self._capture(images, labels, row_weight)
+        if key != self.key:
+            self.model.prefix.grad = None          # (the graph's gradient buffer holds the previous replay's values)
+            return coop_step(self.model, self.clip_model, images, labels, row_weight, self.optimizer)
+        self.x.copy_(images)
+        self.y.copy_(labels)
+        self.w.copy_(row_weight)
+        self.model.prefix.grad = self.grad
+        self.graph.replay()
+        gdist.allreduce_mean_([self.grad])
+        self.optimizer.step()
+        return self.loss

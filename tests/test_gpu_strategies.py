@@ -150,3 +150,29 @@ def test_assign_pseudo_labels_uses_the_sharded_pool_encode(tmp_path, monkeypatch
     want = pl.pseudolabel_from_features(img, txt, m.scale(), list(data.filepaths), [l2i[c] for c in target], 3, argmax_on="logits")
     out = m.assign_pseudo_labels(3, data)
     assert (out.filepaths, out.labels) == want and out.label_id is True and len(want[0]) > 0
+
+
+def test_graphed_coop_step_equals_eager():
+    """steps.GraphedCoopStep (forward + backward replayed from a HIP graph) follows exactly the trajectory of the eager
+    coop_step: same losses and the same prompt after several SGD steps on changing batches."""
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, rng, steps
+    from grip_amd.models import CustomTextEncoder, TextPrefixModel
+    m, _ = clip.load("small", device="cuda")
+    classes = [f"class {i}" for i in range(7)]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    xs = [torch.randn(8, 3, 64, 64, device="cuda", generator=g) for _ in range(5)]
+    ys = [torch.randint(0, 7, (8,), device="cuda", generator=g, dtype=torch.int32) for _ in range(5)]
+    w = torch.full((8,), 1 / 8, device="cuda")
+    out = []
+    for graphed in (False, True):
+        p0 = torch.from_numpy(rng.normal(3, rng.stream_id("gr.p"), (1, 4, 256), 0.0, 0.02)).cuda()
+        tm = TextPrefixModel(p0, CustomTextEncoder(m, "cuda", torch.float32), classes, device="cuda")
+        opt = torch.optim.SGD([tm.prefix], lr=0.1, weight_decay=0.1)
+        step = steps.GraphedCoopStep(tm, m, opt) if graphed else (lambda x, y, ww, _tm=tm, _opt=opt: steps.coop_step(_tm, m, x, y, ww, _opt))
+        losses = [float(step(x, y, w)) for x, y in zip(xs, ys)]
+        losses.append(float(step(xs[0][:5], ys[0][:5], w[:5] * 8 / 5)))       # another batch size: the graphed step falls back to eager
+        out.append((losses, tm.prefix.detach().clone()))
+    (l_e, p_e), (l_g, p_g) = out
+    assert l_e == l_g, (l_e, l_g)
+    assert torch.equal(p_e, p_g)
