@@ -845,6 +845,10 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     static unsigned g_tick = 0;
     int chosen = 0;
     if (!g_prof || (++g_tick & 3u)) return launch_gemm_impl(epi, a, s, &chosen);
+    {   // never put timing events into a stream that is being captured into a HIP graph (steps.GraphedCoopStep)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return launch_gemm_impl(epi, a, s, &chosen);
+    }
     if ((int)g_recs.size() >= PROF_RING) prof_drain(PROF_RING / 2);
     ProfRec r{epi, 2.0 * a.M * (double)a.N * a.K, prof_event(), prof_event()};
     if (!r.a || !r.b) return launch_gemm_impl(epi, a, s, &chosen);
