@@ -855,7 +855,7 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     (void)hipEventRecord(r.a, s);
     const int rc = launch_gemm_impl(epi, a, s, &chosen);
     (void)hipEventRecord(r.b, s);
-    r.epi = chosen * 16 + epi;
+    r.epi = chosen * 16 + ((epi == EPI_BIAS_RESID && a.stat_part) ? (int)EPI_BIAS_RESID_STATS : epi);   // the instantiation that actually ran
     g_recs.push_back(r);
     return rc;
 }

@@ -7,11 +7,15 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --no-cpu-baseline --no-secondary --no-exact > $OUT/bench_line.json 2> $OUT/bench_stderr.log
+if [ "${SKIP_STATS:-0}" != "1" ]; then
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --no-cpu-baseline --no-secondary --no-exact > $OUT/bench_line.json 2> $OUT/bench_stderr.log
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+fi
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
   N=$(echo $C | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$N -o r -- python $R/bench.py --no-cpu-baseline --no-secondary --no-exact --pool 13200 --steps 1 --warmup 0 > /dev/null 2>> $OUT/bench_stderr.log
+  # (--graph 0: rocprofv3 counter collection aborts on HIP-graph replays -- "incomplete dispatches" -- and then hangs; the encode
+  # kernels the counters are wanted for are launched eagerly either way.  timeout: never let a profiler hang eat the box.)
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$N -o r -- python $R/bench.py --no-cpu-baseline --no-secondary --no-exact --graph 0 --pool 13200 --steps 1 --warmup 0 > /dev/null 2>> $OUT/bench_stderr.log
   python3 - "$(find /tmp/prof_$N -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$N.csv" <<'PY'
 import csv, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
@@ -27,5 +31,5 @@ with open(dst, "w", newline="") as f:
         w.writerow([k, c, n, s, s / n])
 PY
 done
-if [ "${FULL_LINE:-1}" = "1" ]; then python $R/bench.py > $OUT/bench_line_full.json 2>> $OUT/bench_stderr.log; fi
+if [ "${FULL_LINE:-1}" = "1" ]; then timeout 900 python $R/bench.py > $OUT/bench_line_full.json 2>> $OUT/bench_stderr.log; fi
 ls -la $OUT
