@@ -326,3 +326,65 @@ int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, in
 #undef GRIP_ATTN
     return GRIP_ERR_ARG;
 }
+
+
+// ---- Attention for ONE query row per sequence (f16 in, f32 math, f16 out): the last block of a tower at inference.  Only the
+// CLS row (vision) / EOT row (text) of the final residual stream is ever read (models/clip_encoders.py:189 and :86-89), and after
+// the last block's attention rows no longer mix, so that block needs its attention output, out-proj and MLP for that row alone
+// (keys and values still come from every row).  One wave per (sequence, head): lanes over keys for the scores (q broadcast
+// from LDS), wave-wide softmax, lanes over the 64 head dims for P.V.
+__global__ __launch_bounds__(64) void attn_row_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ qrows, const int32_t* __restrict__ row_index,
+                                                     half_t* __restrict__ out, int S, int H, int causal) {
+    extern __shared__ float sm[];         // [64] q, [S] probabilities
+    float* qs = sm;
+    float* ps = sm + 64;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * 64;
+    const size_t ld = (size_t)3 * D;
+    const int r = row_index ? row_index[b] : 0;
+    const half_t* base = qkv + (size_t)b * S * ld + h * 64;
+    // the query row: from the compact [B, D] matrix when the caller projected only those rows, else from the packed qkv
+    qs[lane] = (float)(qrows ? qrows[(size_t)b * D + h * 64 + lane] : base[(size_t)r * ld + lane]) * 0.125f;
+    __syncthreads();
+    const int n_keys = causal ? r + 1 : S;
+    float m = -INFINITY;
+    for (int j = lane; j < n_keys; j += 64) {
+        const half8* kr = (const half8*)(base + (size_t)j * ld + D);
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half8 kv = kr[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qs[c * 8 + e], (float)kv[e], a);
+        }
+        ps[j] = a;
+        m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int j = lane; j < n_keys; j += 64) {
+        const float p = __expf(ps[j] - m);
+        ps[j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    float o = 0.f;
+    const half_t* vbase = base + 2 * D + lane;
+    int j = 0;
+    for (; j + 4 <= n_keys; j += 4) {       // four independent row loads in flight
+        const float v0 = (float)vbase[(size_t)j * ld], v1 = (float)vbase[(size_t)(j + 1) * ld], v2 = (float)vbase[(size_t)(j + 2) * ld], v3 = (float)vbase[(size_t)(j + 3) * ld];
+        o = __builtin_fmaf(ps[j], v0, o); o = __builtin_fmaf(ps[j + 1], v1, o); o = __builtin_fmaf(ps[j + 2], v2, o); o = __builtin_fmaf(ps[j + 3], v3, o);
+    }
+    for (; j < n_keys; ++j) o = __builtin_fmaf(ps[j], (float)vbase[(size_t)j * ld], o);
+    out[(size_t)b * D + h * 64 + lane] = (half_t)(o / sum);
+}
+
+int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s) {
+    GRIP_REQUIRE(B >= 1 && S >= 1 && H >= 1, "attention_row: bad shape");
+    hipLaunchKernelGGL(attn_row_kernel, dim3(B * H), dim3(64), (size_t)(64 + S) * sizeof(float), s, qkv, qrows, row_index, out, S, H, causal);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

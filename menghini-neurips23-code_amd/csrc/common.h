@@ -182,6 +182,8 @@ int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int
 
 // attention (attention.hip / attention_f32.hip): qkv [B*S, 3*D] -> out [B*S, D]
 int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s);
+int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s);
+int launch_gather_rows(const half_t* x, const int32_t* row_index, int row_stride, half_t* out, int n_rows, int d, hipStream_t s);
 int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s);
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
 int launch_attention_bwd_tiled(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);

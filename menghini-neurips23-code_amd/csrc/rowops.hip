@@ -328,3 +328,20 @@ int launch_ln_fold_weights(const half_t* W, const float* gamma, const float* bet
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
+
+// out[b] = x[b * row_stride + (row_index ? row_index[b] : 0)]  (f16 rows of width d): the CLS / EOT rows of the stream, compacted.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const half_t* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
+                                                          half_t* __restrict__ out, int n_rows, int d8) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_rows * d8) return;
+    const int b = idx / d8, c = idx - b * d8;
+    const size_t src = (size_t)b * row_stride + (row_index ? row_index[b] : 0);
+    ((half8*)out)[(size_t)b * d8 + c] = ((const half8*)x)[src * d8 + c];
+}
+
+int launch_gather_rows(const half_t* x, const int32_t* row_index, int row_stride, half_t* out, int n_rows, int d, hipStream_t s) {
+    GRIP_REQUIRE(d % 8 == 0, "gather_rows: width %% 8 != 0");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_rows * (d / 8) + 255) / 256), dim3(256), 0, s, x, row_index, row_stride, out, n_rows, d / 8);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

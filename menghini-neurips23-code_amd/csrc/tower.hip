@@ -9,6 +9,7 @@
 // qkv [M, 3d], attention output, MLP hidden [M, 4d]) f16.  Row counts are padded to the 128-row GEMM
 // tile in the workspace; padding rows are never stored to and never read back.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
@@ -162,6 +163,10 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     half_t* cls16 = nullptr;   // [round_up(batch,128), d]
     half_t* patches = nullptr; // alias of h
     float* patch_out = nullptr;// alias of qkv
+    half_t* row_x = nullptr;   // compact last-block buffers (inference, f16 towers): [Bp, d] stream rows, [Bp, d] attention rows,
+    half_t* row_att = nullptr; // [Bp, d] LayerNorm output, [Bp, 4d] MLP hidden
+    half_t* row_xn = nullptr;
+    half_t* row_h = nullptr;
     float* stat_part = nullptr;// [Mp, d/64, 2] partial row sums emitted by the residual GEMM epilogues (f16 towers)
     float* rowstat = nullptr;  // [Mp, 2] (mean, rstd) of the residual stream's rows, consumed by the LayerNorm-folded GEMMs
     // train-mode saves, one per layer (x_in has layers+1 entries)
@@ -225,6 +230,12 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * es); w.att = (half_t*)take(w.Mp * d * es); }
     w.h = (half_t*)take(w.Mp * 4 * d * es);
     w.cls16 = (half_t*)take(Bp * d * es);
+    if (!t->f32 && !train) {
+        w.row_x = (half_t*)take(Bp * d * 2);
+        w.row_att = (half_t*)take(Bp * d * 2);
+        w.row_xn = (half_t*)take(Bp * d * 2);
+        w.row_h = (half_t*)take(Bp * 4 * d * 2);
+    }
     if (!t->f32) {
         w.stat_part = (float*)take(w.Mp * (d / 64) * 2 * sizeof(float));
         w.rowstat = (float*)take(w.Mp * 2 * sizeof(float));
@@ -325,7 +336,7 @@ extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix
 // into the QKV / c_fc GEMMs, whose A operand is the raw stream (EPI_LNFOLD_*: rstd (x W'^T - mean colsum(W')) + (W beta + b)).
 // That removes two full read + write passes over the stream per block (8.8 % of the pool encode's GPU time in round 1).
 // Exact (f32) towers keep the literal LayerNorm -> GEMM sequence.
-static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipStream_t s, resid_t** x_final) {
+static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, const int32_t* read_rows, hipStream_t s, resid_t** x_final, bool* compact) {
     const int d = t->D.width, H = t->D.heads, f = t->f32;
     const float* F = t->w32;
     resid_t* x = x0;
@@ -335,9 +346,44 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, hipS
     // those steps 5 % slower (r02: VPT step 3.8 -> 4.0 ms with the fold).  The switch is the MODE, never the batch size: every
     // inference call computes a row the same way whatever chunk it arrives in (sharded / re-chunked encodes stay bit-identical).
     const bool fold = !f && !w.train;
+    // Last block at inference: only ONE row per sequence of the final stream is ever read (CLS: ln_post(x[:, 0]),
+    // models/clip_encoders.py:189; EOT: :86-89), and past the block's attention rows do not mix.  So the block computes K and V for
+    // every row but its attention output, out-proj, LayerNorm and MLP for that row alone (M = batch instead of batch x S):
+    // 2.2 of the block's 2.9 GFLOP per ViT-B/16 image are never issued, the embedding is unchanged.  GRIP_LAST_BLOCK_FULL=1
+    // computes the whole block as the reference does (A/B; the tests hold the two paths equal).
+    static const bool last_full = getenv("GRIP_LAST_BLOCK_FULL") && atoi(getenv("GRIP_LAST_BLOCK_FULL")) != 0;
+    const bool rows_only = fold && !last_full;
+    *compact = false;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
         const bool last = l + 1 == t->D.layers;
+        if (last && rows_only) {
+            // K and V of every row (columns d .. 3d of the packed projection); Q only for the rows that are read
+            GemmArgs a{};
+            a.A = x; a.W = t->w16 + lw.in_wG + (int64_t)d * d; a.M = w.M; a.m_pad = w.Mp; a.N = 2 * d; a.K = d; a.bias = F + lw.in_bb + d; a.colsum = F + lw.in_cs + d;
+            a.rowstat = w.rowstat; a.out = w.qkv + d; a.ldc = 3 * d;
+            RUN(launch_gemm(EPI_LNFOLD_F16, a, s));
+            RUN(launch_gather_rows(x, read_rows, w.S, w.row_x, w.batch, d, s));
+            RUN(launch_layernorm_f16(w.row_x, F + lw.ln1_g, F + lw.ln1_b, w.row_xn, 0, w.batch, d, s));
+            a = GemmArgs{};
+            a.A = w.row_xn; a.W = t->w16 + lw.in_w; a.M = w.batch; a.m_pad = round_up64(w.batch, 256); a.N = d; a.K = d; a.bias = F + lw.in_b; a.out = w.row_h; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_F16, a, s));
+            RUN(launch_attention_row(w.qkv, w.row_h, read_rows, w.row_att, w.batch, w.S, H, causal, s));
+            const int64_t Bp = round_up64(w.batch, 256);
+            a = GemmArgs{};
+            a.A = w.row_att; a.W = t->w16 + lw.out_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_RESID, a, s));
+            RUN(launch_layernorm_f16(w.row_x, F + lw.ln2_g, F + lw.ln2_b, w.row_xn, 0, w.batch, d, s));
+            a = GemmArgs{};
+            a.A = w.row_xn; a.W = t->w16 + lw.fc_w; a.M = w.batch; a.m_pad = Bp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.row_h; a.ldc = 4 * d;
+            RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
+            a = GemmArgs{};
+            a.A = w.row_h; a.W = t->w16 + lw.proj_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_RESID, a, s));
+            x = w.row_x;
+            *compact = true;
+            break;
+        }
         half_t* qkv = w.train ? w.qkv_l[(size_t)l] : w.qkv;
         half_t* att = w.train ? w.att_l[(size_t)l] : w.att;
         resid_t* x_mid = w.train ? w.x_mid[(size_t)l] : x;
@@ -421,8 +467,9 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         resid_t* x0 = train ? w.x_in[0] : w.x;
         RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, train ? nullptr : w.rowstat, batch, G2, d, s));
         resid_t* xf = nullptr;
-        RUN(run_blocks(t, w, x0, /*causal=*/0, s, &xf));
-        RUN(launch_gather_ln_f16(xf, nullptr, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, batch, d, s));
+        bool compact = false;
+        RUN(run_blocks(t, w, x0, /*causal=*/0, nullptr, s, &xf, &compact));
+        RUN(launch_gather_ln_f16(xf, nullptr, compact ? 1 : w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, batch, d, s));
         a = GemmArgs{};
         a.f32 = f; a.A = w.cls16; a.W = t->wop(t->L.projT); a.M = batch; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
         RUN(launch_gemm(EPI_F32, a, s));
@@ -447,8 +494,9 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         resid_t* x0 = train ? w.x_in[0] : w.x;
         RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, train ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s));
         resid_t* xf = nullptr;
-        RUN(run_blocks(t, w, x0, /*causal=*/1, s, &xf));
-        RUN(launch_gather_ln_f16(xf, eot_index, w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, n_class, d, s));
+        bool compact = false;
+        RUN(run_blocks(t, w, x0, /*causal=*/1, eot_index, s, &xf, &compact));
+        RUN(launch_gather_ln_f16(xf, compact ? nullptr : eot_index, compact ? 1 : w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, n_class, d, s));
         GemmArgs a{};
         a.f32 = f; a.A = w.cls16; a.W = t->wop(t->L.projT); a.M = n_class; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
         RUN(launch_gemm(EPI_F32, a, s));

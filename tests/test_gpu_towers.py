@@ -199,3 +199,40 @@ def test_clip_load_from_a_torchscript_archive(tmp_path, monkeypatch, models):
         clip.load("tiny", device="cuda")
     with pytest.raises(RuntimeError, match="no BPE vocabulary"):        # real weights + the stand-in tokenizer would be garbage
         clip.tokenize(["a photo of a forest"])
+
+
+def test_last_block_rows_only_equals_full_block(tmp_path):
+    """Inference computes the last block's attention output / out-proj / MLP only for the row that is read (CLS or EOT; K and V for
+    every row).  GRIP_LAST_BLOCK_FULL=1 computes the whole block as the reference does: same embeddings (the only numerical
+    difference is the single-row attention in f32 instead of the f16-probability MFMA kernel)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    script = tmp_path / "dump.py"
+    script.write_text(r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["GRIP_REPO"])
+import grip_amd
+from grip_amd import clip, rng
+out = {}
+for name, res in (("small", 64), ("ViT-B/16", 224)):
+    m, _ = clip.load(name, device="cuda")
+    x = torch.from_numpy(rng.normal(9, rng.stream_id("lb.x." + name), (5, 3, res, res))).cuda()
+    p = torch.from_numpy(rng.normal(9, rng.stream_id("lb.p." + name), (4, m.visual.tower.width), 0.0, 0.05)).cuda()
+    tok = clip.tokenize(["a photo of a forest", "x x river bank", "highway"]).cuda()
+    with torch.no_grad():
+        out[name] = [m.encode_image(x).cpu(), m.visual(x, p).cpu(), m.encode_text(tok).cpu()]
+torch.save(out, os.environ["GRIP_OUT"])
+''')
+    res = {}
+    for full in ("0", "1"):
+        env = dict(os.environ, GRIP_REPO=REPO, GRIP_OUT=str(tmp_path / f"o{full}.pt"), GRIP_LAST_BLOCK_FULL=full, PYTHONPATH=REPO)
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[full] = torch.load(str(tmp_path / f"o{full}.pt"))
+    for name in res["0"]:
+        for a, b in zip(res["0"][name], res["1"][name]):
+            cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
+            assert (1 - cos).max().item() <= 2e-6 and ((a - b).norm() / b.norm()).item() <= 2e-3, (name, (1 - cos).max().item())
+            assert not torch.equal(a, b)        # the two paths really are different code
