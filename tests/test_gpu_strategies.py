@@ -176,3 +176,26 @@ def test_graphed_coop_step_equals_eager():
     (l_e, p_e), (l_g, p_g) = out
     assert l_e == l_g, (l_e, l_g)
     assert torch.equal(p_e, p_g)
+
+
+@pytest.mark.parametrize("encoder,model,extra", [("ViT-L/14@336px", "grip_textual", {}), ("ViT-B/16", "grip_multimodal", {"LR": "0.01"})])
+def test_baseline_configs_run_end_to_end_at_real_dimensions(tmp_path, encoder, model, extra):
+    """BASELINE.json configs[4] (GRIP textual TRZSL on ViT-L/14@336px) and configs[3] (GRIP multimodal / UPT TRZSL on ViT-B/16) through
+    the reference-named entry point run_main_trzsl.py at the REAL tower dimensions (tiny synthetic pool, one epoch per GRIP
+    iteration): pseudolabels from frozen CLIP, prompt training, re-labelling with the trained prompts through the sharded pool
+    encode, evaluation, and the reference's on-disk artefacts."""
+    import glob
+    import pickle
+    env = dict(os.environ, VIS_ENCODER=encoder, MODEL=model, EPOCHS="1", STEP_QUANTILE="50", N_PSEUDOSHOTS="2", BATCH_SIZE="4", PYTHONPATH=REPO, **extra)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "run_main_trzsl.py"), "--synthetic", "4", "--classes", "5"], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["encoder"] == encoder and res["model"] == model and res["paradigm"] == "trzsl"
+    assert {"seen_accuracy", "unseen_accuracy", "harmonic_mean"} <= set(res) and res["n_test"] > 0
+    enc = encoder.replace("/", "")
+    pls = sorted(glob.glob(str(tmp_path / "pseudolabels" / f"Synthetic_trzsl_{model}_{enc}_iter_*_opt_1_spl_500.pickle")))
+    assert len(pls) == 2, os.listdir(tmp_path / "pseudolabels")          # STEP_QUANTILE 50 -> two GRIP iterations, reference file names
+    assert set(pickle.load(open(pls[0], "rb"))) == {"filepaths", "labels"}
+    prompts = glob.glob(str(tmp_path / "trained_prompts" / f"Synthetic_trzsl_{model}_{enc}_iter_2_*"))
+    assert len(prompts) == (8 if model == "grip_multimodal" else 1), prompts
