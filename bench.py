@@ -317,6 +317,8 @@ def secondary_block(loop, lib):
     y = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
     out["vpt_step"] = dict(timed(lambda: steps.vpt_step(im, txt, scale, x, y, w, opt), 20, B, 2 * B * 38.09e9),
                            workload="configs[2] RESISC45-shaped VPT step: B = 16, 16 visual prompt tokens, C = 45, ViT-B/16 fwd + dgrad bwd + SGD")
+    gv = steps.GraphedVptStep(im, txt, scale, opt)
+    out["vpt_step"]["ms_hip_graph"] = timed(lambda: gv(x, y, w), 20, B, 2 * B * 38.09e9)["ms"]
     C = 47
     classes = [f"class_{i}" for i in range(C)]
     enc = CustomTextEncoder(m, dev, torch.float32)
@@ -326,6 +328,9 @@ def secondary_block(loop, lib):
     y2 = torch.randint(0, C, (B,), device=dev, dtype=torch.int32)
     out["upt_step"] = dict(timed(lambda: steps.upt_step(um, scale, x, y2, w, opt2), 20, B, 2 * B * 35.87e9 + 2 * C * F_TXT),
                            workload="configs[3] DTD-shaped UPT step: B = 16, Pt = Pv = 4, C = 47, both towers fwd + bwd, mixer, SGD")
+    gu = steps.GraphedUptStep(um, scale, opt2)
+    out["upt_step"]["ms_hip_graph"] = timed(lambda: gu(x, y2, w), 20, B, 2 * B * 35.87e9 + 2 * C * F_TXT)["ms"]
+    del gv, gu
     del im, um, opt, opt2
     big, _ = clip.load("ViT-L/14@336px", device=dev)
     xl = torch.randn(128, 3, 336, 336, device=dev)

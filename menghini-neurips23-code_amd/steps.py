@@ -82,66 +82,142 @@ def upt_step(model, logit_scale, images, labels, row_weight, optimizer):
     return _finish(loss, [p for p in model.parameters() if p.requires_grad], optimizer)
 
 
-class GraphedCoopStep:
-    """coop_step with its forward + backward captured ONCE in a HIP graph and replayed per step (shapes are static within an
-    epoch: same batch size, same class list).  The CoOp step is ~330 launches of 10-25 us on two streams; replaying them
-    as one graph removes the per-launch host cost and the launch gaps, nothing else changes: the captured kernels are the
-    ones coop_step launches, the prompt-gradient all-reduce and the optimizer step stay outside the graph (eager), so the
-    same object serves one GPU and N.  A batch of another size falls back to the eager step.
+class GraphedStep:
+    """A prompt step whose forward + backward is captured ONCE in a HIP graph and replayed per step (shapes are static within an
+    epoch: same batch size, same class list).  A CoOp step is ~330 launches of 10-25 us on two streams, a UPT step adds the
+    mixer's dozens of tiny torch kernels; replaying them as one graph removes the per-launch host cost, nothing else changes: the
+    captured kernels are the ones the eager step launches, the prompt-gradient all-reduce and the optimizer step stay outside
+    the graph (eager), so the same object serves one GPU and N.  A batch of another shape falls back to the eager step.
 
     Static inputs: images [B,3,R,R] / labels [B] / row weights [B] are copied into fixed buffers before each replay; the
-    prompt parameter is read in place, its .grad is written in place."""
+    trainable parameters are read in place, their .grad buffers are written in place.  Subclasses give `forward_logits`
+    (static inputs -> logits), `params` and the eager fallback."""
 
-    def __init__(self, model, clip_model, optimizer):
-        self.model, self.clip_model, self.optimizer = model, clip_model, optimizer
-        self.scale = clip_model.logit_scale.exp().item()
+    def __init__(self, optimizer):
+        self.optimizer = optimizer
         self.graph = None
         self.key = None
 
+    # -- subclass interface
+    def params(self):
+        raise NotImplementedError
+
+    def forward_logits(self):
+        raise NotImplementedError
+
+    def eager(self, images, labels, row_weight):
+        raise NotImplementedError
+
+    def shape_key(self, images):
+        return (tuple(images.shape), images.dtype)
+
+    # -- machinery
     def _body(self):
-        side = _side_stream(self.x.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            image_features = self.clip_model.encode_image(self.x)
-        text_features = self.model(self.model.classes)
-        torch.cuda.current_stream().wait_stream(side)
-        logits = CosineHeadFn.apply(image_features, text_features, self.scale)
-        loss = WeightedCEFn.apply(logits, self.y, self.w)
+        loss = WeightedCEFn.apply(self.forward_logits(), self.y, self.w)
         loss.backward()
         return loss.detach()
 
     def _capture(self, images, labels, row_weight):
         dev = images.device
         self.x, self.y, self.w = images.clone(), labels.to(torch.int32).clone(), row_weight.to(torch.float32).clone()
-        self.key = (tuple(images.shape), images.dtype, tuple(self.model.classes))
-        prefix = self.model.prefix
+        self.key = self.shape_key(images)
+        ps = self.params()
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(warm):              # warm-up off the default stream: workspaces, lazy kernel attributes, cached token ids
             for _ in range(2):
-                prefix.grad = None
+                for p in ps:
+                    p.grad = None
                 self._body()
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
-        prefix.grad = torch.zeros_like(prefix)     # the captured backward accumulates into this buffer
+        for p in ps:
+            p.grad = torch.zeros_like(p)           # the captured backward accumulates into these buffers
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            prefix.grad.zero_()
+            for p in ps:
+                p.grad.zero_()
             self.loss = self._body()
-        self.grad = prefix.grad
+        self.grads = [p.grad for p in ps]
 
     def __call__(self, images, labels, row_weight):
-        key = (tuple(images.shape), images.dtype, tuple(self.model.classes))
         if self.graph is None:
             self._capture(images, labels, row_weight)
-        if key != self.key:
-            self.model.prefix.grad = None          # (the graph's gradient buffer holds the previous replay's values)
-            return coop_step(self.model, self.clip_model, images, labels, row_weight, self.optimizer)
+        if self.shape_key(images) != self.key:
+            for p in self.params():
+                p.grad = None                      # (the graph's gradient buffers hold the previous replay's values)
+            return self.eager(images, labels, row_weight)
         self.x.copy_(images)
         self.y.copy_(labels)
         self.w.copy_(row_weight)
-        self.model.prefix.grad = self.grad
+        for p, g in zip(self.params(), self.grads):
+            p.grad = g
         self.graph.replay()
-        gdist.allreduce_mean_([self.grad])
+        gdist.allreduce_mean_(self.grads)
         self.optimizer.step()
         return self.loss
+
+
+class GraphedCoopStep(GraphedStep):
+    """coop_step (textual prompt: text tower forward + backward, frozen image tower on a side stream) replayed from a HIP graph."""
+
+    def __init__(self, model, clip_model, optimizer):
+        super().__init__(optimizer)
+        self.model, self.clip_model = model, clip_model
+        self.scale = clip_model.logit_scale.exp().item()
+
+    def params(self):
+        return [self.model.prefix]
+
+    def shape_key(self, images):
+        return (tuple(images.shape), images.dtype, tuple(self.model.classes))
+
+    def forward_logits(self):
+        side = _side_stream(self.x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            image_features = self.clip_model.encode_image(self.x)
+        text_features = self.model(self.model.classes)
+        torch.cuda.current_stream().wait_stream(side)
+        return CosineHeadFn.apply(image_features, text_features, self.scale)
+
+    def eager(self, images, labels, row_weight):
+        return coop_step(self.model, self.clip_model, images, labels, row_weight, self.optimizer)
+
+
+class GraphedVptStep(GraphedStep):
+    """vpt_step (visual prompt: image tower forward + backward; text features fixed for the epoch) replayed from a HIP graph."""
+
+    def __init__(self, model, text_features, logit_scale, optimizer):
+        super().__init__(optimizer)
+        self.model, self.text_features, self.scale = model, text_features, float(logit_scale)
+
+    def params(self):
+        return [self.model.prefix]
+
+    def forward_logits(self):
+        return CosineHeadFn.apply(self.model(self.x), self.text_features, self.scale)
+
+    def eager(self, images, labels, row_weight):
+        return vpt_step(self.model, self.text_features, self.scale, images, labels, row_weight, self.optimizer)
+
+
+class GraphedUptStep(GraphedStep):
+    """upt_step (multimodal prompt: mixer + both towers forward and backward, towers on two streams) replayed from a HIP graph."""
+
+    def __init__(self, model, logit_scale, optimizer):
+        super().__init__(optimizer)
+        self.model, self.scale = model, float(logit_scale)
+
+    def params(self):
+        return [p for p in self.model.parameters() if p.requires_grad]
+
+    def shape_key(self, images):
+        return (tuple(images.shape), images.dtype, tuple(self.model.classes))
+
+    def forward_logits(self):
+        text_features, image_features = self.model(self.x, self.model.classes)
+        return CosineHeadFn.apply(image_features, text_features, self.scale)
+
+    def eager(self, images, labels, row_weight):
+        return upt_step(self.model, self.scale, images, labels, row_weight, self.optimizer)

@@ -199,3 +199,35 @@ def test_baseline_configs_run_end_to_end_at_real_dimensions(tmp_path, encoder, m
     assert set(pickle.load(open(pls[0], "rb"))) == {"filepaths", "labels"}
     prompts = glob.glob(str(tmp_path / "trained_prompts" / f"Synthetic_trzsl_{model}_{enc}_iter_2_*"))
     assert len(prompts) == (8 if model == "grip_multimodal" else 1), prompts
+
+
+def test_graphed_vpt_and_upt_steps_equal_eager():
+    """GraphedVptStep / GraphedUptStep against the eager steps: identical losses and parameters after several SGD steps (the UPT
+    graph also holds the torch mixer and both towers on two streams)."""
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, rng, steps
+    from grip_amd.models import CustomImageEncoder, CustomTextEncoder, ImagePrefixModel, UPTModel
+    m, _ = clip.load("small", device="cuda")
+    classes = [f"class {i}" for i in range(6)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    xs = [torch.randn(8, 3, 64, 64, device="cuda", generator=g) for _ in range(4)]
+    ys = [torch.randint(0, 6, (8,), device="cuda", generator=g, dtype=torch.int32) for _ in range(4)]
+    w = torch.full((8,), 1 / 8, device="cuda")
+    txt = m.encode_text(clip.tokenize([f"a photo of a {c}" for c in classes]).cuda())
+    N = lambda name, shape: torch.from_numpy(rng.normal(4, rng.stream_id(name), shape, 0.0, 0.02)).cuda()   # noqa: E731
+    res = {}
+    for graphed in (False, True):
+        im = ImagePrefixModel(N("gv.p", (4, 256)), CustomImageEncoder(m.visual), device="cuda")
+        opt = torch.optim.SGD([im.prefix], lr=0.1, weight_decay=0.1)
+        step = steps.GraphedVptStep(im, txt, 100.0, opt) if graphed else (lambda x, y, ww, _m=im, _o=opt: steps.vpt_step(_m, txt, 100.0, x, y, ww, _o))
+        losses = [float(step(x, y, w)) for x, y in zip(xs, ys)]
+        torch.manual_seed(7)
+        um = UPTModel(N("gu.c", (1, 4, 256)), N("gu.v", (1, 4, 256)), None, CustomImageEncoder(m.visual), CustomTextEncoder(m, "cuda", torch.float32),
+                      classes, 128, device="cuda", dtype=torch.float32)
+        opt2 = torch.optim.SGD([p for p in um.parameters() if p.requires_grad], lr=0.01, weight_decay=0.1)
+        step2 = steps.GraphedUptStep(um, 100.0, opt2) if graphed else (lambda x, y, ww, _m=um, _o=opt2: steps.upt_step(_m, 100.0, x, y, ww, _o))
+        losses2 = [float(step2(x, y, w)) for x, y in zip(xs, ys)]
+        res[graphed] = (losses, im.prefix.detach().clone(), losses2, um.coop_embeddings.detach().clone(), um.proj_vpt_post.weight.detach().clone())
+    e, gr = res[False], res[True]
+    assert e[0] == gr[0] and torch.equal(e[1], gr[1])
+    assert e[2] == gr[2] and torch.equal(e[3], gr[3]) and torch.equal(e[4], gr[4])
