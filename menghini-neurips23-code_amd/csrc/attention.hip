@@ -371,15 +371,27 @@ __global__ __launch_bounds__(64) void attn_row_kernel(const half_t* __restrict__
     }
     sum = wave_sum(sum);
     __syncthreads();
-    float o = 0.f;
-    const half_t* vbase = base + 2 * D + lane;
-    int j = 0;
-    for (; j + 4 <= n_keys; j += 4) {       // four independent row loads in flight
-        const float v0 = (float)vbase[(size_t)j * ld], v1 = (float)vbase[(size_t)(j + 1) * ld], v2 = (float)vbase[(size_t)(j + 2) * ld], v3 = (float)vbase[(size_t)(j + 3) * ld];
-        o = __builtin_fmaf(ps[j], v0, o); o = __builtin_fmaf(ps[j + 1], v1, o); o = __builtin_fmaf(ps[j + 2], v2, o); o = __builtin_fmaf(ps[j + 3], v3, o);
+    // P.V: lane = (key group lane >> 3, 8-wide slice of the head dim lane & 7): 16-byte loads, eight keys in flight per step; the
+    // eight key groups are then folded with three xor-shuffles (lanes 8, 16, 32 apart hold the same slice).
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int kg = lane >> 3, ch = lane & 7;
+    for (int j = kg; j < n_keys; j += 8) {
+        const half8 v = *(const half8*)(base + (size_t)j * ld + 2 * D + ch * 8);
+        const float p = ps[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)v[e], acc[e]);
     }
-    for (; j < n_keys; ++j) o = __builtin_fmaf(ps[j], (float)vbase[(size_t)j * ld], o);
-    out[(size_t)b * D + h * 64 + lane] = (half_t)(o / sum);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8);
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (kg == 0) {
+        const float inv = 1.0f / sum;
+        *(half8*)(out + (size_t)b * D + h * 64 + ch * 8) = (half8){(half_t)(acc[0] * inv), (half_t)(acc[1] * inv), (half_t)(acc[2] * inv), (half_t)(acc[3] * inv),
+                                                                   (half_t)(acc[4] * inv), (half_t)(acc[5] * inv), (half_t)(acc[6] * inv), (half_t)(acc[7] * inv)};
+    }
 }
 
 int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s) {
