@@ -158,7 +158,13 @@ struct GemmArgs {
                            // per 64-column wave tile; ln_stats_finalize turns them into rowstat for the consuming GEMM
     const float* rowstat;  // EPI_LNFOLD_*: [M, 2] (mean, rstd) of A's rows
     const float* colsum;   // EPI_LNFOLD_*: [N]
+    // Split-K (EPI_F32 on the small-M kernels only): ksplit > 1 launches ksplit workgroups per output tile, each contracting
+    // K/ksplit and writing its partial product to out + split * split_stride (floats); the consumer sums the partials
+    // in a fixed order (launch_ln_bwd_add).  gemm_pick_ksplit chooses the factor.
+    int ksplit;
+    int64_t split_stride;
 };
+int gemm_pick_ksplit(int M, int N, int K);
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);
@@ -189,7 +195,7 @@ int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out
 int launch_attention_bwd_tiled(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
 // backward row kernels (rowops_bwd.hip)
 int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
-int launch_ln_bwd_add(const resid_t* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s);
+int launch_ln_bwd_add(const resid_t* x, const float* dln, int parts, int64_t part_stride, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s);
 int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
                           int n, int d, hipStream_t s);
 int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* gamma, const float* scale, float* grad, int B, int S, int P, int d, hipStream_t s);

@@ -270,13 +270,20 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
     f32x4 acc[WMF][4];
     init_acc<EPI, WMF>(g, acc, n0 + wc * 64, lane);
 
-    const int nk = g.K / BK;
-    stage(0, 0);
+    int nk = g.K / BK, kt0 = 0;
+    if constexpr (EPI == EPI_F32) {
+        if (gridDim.y > 1) {       // split-K: this workgroup contracts k tiles [kt0, kt0 + nk) into partial buffer blockIdx.y
+            nk /= (int)gridDim.y;
+            kt0 = (int)blockIdx.y * nk;
+            g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
+        }
+    }
+    stage(0, kt0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of tile kt has landed (explicit: never left to the compiler)
         __syncthreads();  // tile kt visible to every wave, tile kt-1 fully read
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+        if (kt + 1 < nk) stage(buf ^ 1, kt0 + kt + 1);
         const half_t* st = lds + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -982,6 +989,20 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
 
 // variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage ring), 3 = 256x128x32 (3-stage ring), 4 = 64x128x64 (2-stage),
 //          5 = 256x256x64 (2-stage, whole-line DMA), 6 = the same, persistent
+// Split-K factor for an EPI_F32 product whose output has too few 64x128 tiles to fill 256 CUs x 3 workgroups while K is
+// long (the input-gradient GEMMs of the prompt steps: 136 tiles x 32 k-steps at M = 2 142, N = 512, K = 2 048): the
+// largest factor that keeps >= 4 k-steps per workgroup and <= 768 workgroups.
+int gemm_pick_ksplit(int M, int N, int K) {
+    static const int off = getenv("GRIP_GEMM_KSPLIT") ? atoi(getenv("GRIP_GEMM_KSPLIT")) : -1;   // developer A/B: 1 disables
+    if (off == 1) return 1;
+    const int64_t tiles = (int64_t)((M + 63) / 64) * (N / BN);
+    const int nk = K / BK;
+    int best = 1;
+    for (int f : {2, 3, 4, 6, 8})
+        if (nk % f == 0 && nk / f >= 4 && tiles * f <= 768) best = f;
+    return best;
+}
+
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
     if (epi == EPI_BIAS_RESID && a.stat_part) epi = EPI_BIAS_RESID_STATS;
     GRIP_REQUIRE(epi != EPI_BIAS_RESID_STATS || (a.stat_part && a.N % 64 == 0), "gemm: row statistics need stat_part and N %% 64 == 0");
@@ -1014,6 +1035,12 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
             }
         }
     }
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    if (ksplit > 1) {
+        GRIP_REQUIRE(epi == EPI_F32 && (a.K / BK) % ksplit == 0 && a.split_stride >= (int64_t)a.M * a.ldc,
+                     "gemm: split-K needs EPI_F32, (K/64) %% ksplit == 0 and a partial stride >= M*ldc (K=%d ksplit=%d)", a.K, ksplit);
+        if (variant != 1) variant = 4;
+    }
     if (variant == 5 && epi == EPI_BIAS_RESID_STATS) variant = 6;   // the one-tile-per-workgroup 64-wide kernel has no registers left for the statistics
     *chosen = variant;
     if (variant == 2) {
@@ -1034,7 +1061,7 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
     }
     const int bmt = variant == 4 ? 64 : 128;
     const int tiles_m = (a.M + bmt - 1) / bmt, tiles_n = a.N / BN;
-    dim3 grid(tiles_m * tiles_n), block(256);
+    dim3 grid(tiles_m * tiles_n, ksplit), block(256);
 #define GRIP_GEMM_CASE(E)                                                                                  \
     case E:                                                                                                \
         if (variant == 4) hipLaunchKernelGGL((gemm_f16_kernel<E, 2>), grid, block, 0, s, a, tiles_m, tiles_n); \

@@ -19,7 +19,7 @@ __device__ __forceinline__ f32x4 load4b(const half_t* p, int i) {
 
 template <int NV, typename XT>
 __device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x4* __restrict__ dyr, const f32x4* __restrict__ gamma,
-                                           int lane, int d4, int d, f32x4 (&dx)[NV]) {
+                                           int lane, int d4, int d, f32x4 (&dx)[NV], int parts = 1, size_t part_stride4 = 0) {
     f32x4 x[NV];
     float s = 0.f;
 #pragma unroll
@@ -36,7 +36,9 @@ __device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
             x[i] = x[i] * rstd;                                    // xhat
-            dx[i] = dyr[lane + 64 * i] * gamma[lane + 64 * i];     // g
+            f32x4 dy = dyr[lane + 64 * i];
+            for (int p = 1; p < parts; ++p) dy += dyr[p * part_stride4 + lane + 64 * i];   // split-K partials, fixed order
+            dx[i] = dy * gamma[lane + 64 * i];                     // g
             a += dx[i][0] + dx[i][1] + dx[i][2] + dx[i][3];
             b += dx[i][0] * x[i][0] + dx[i][1] * x[i][1] + dx[i][2] * x[i][2] + dx[i][3] * x[i][3];
         }
@@ -47,16 +49,16 @@ __device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x
         if (lane + 64 * i < d4) dx[i] = (dx[i] - a - x[i] * b) * rstd;
 }
 
-// dx[r] += LNbwd(dln[r]; x[r]);  dxh[r] = f16(dx[r])            (r < M)
+// dx[r] += LNbwd(sum_p dln[p][r]; x[r]);  dxh[r] = f16(dx[r])            (r < M; p over the split-K partials of the producer)
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_add_kernel(const resid_t* __restrict__ x, const float* __restrict__ dln, const float* __restrict__ gamma,
-                                                         float* __restrict__ dx, half_t* __restrict__ dxh, int M, int d) {
+                                                         float* __restrict__ dx, half_t* __restrict__ dxh, int M, int d, int parts, size_t part_stride4) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int d4 = d >> 2;
     f32x4 g[NV];
-    ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g);
+    ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g, parts, part_stride4);
     f32x4* o = (f32x4*)(dx + (size_t)row * d);
     half4* oh = (half4*)(dxh + (size_t)row * d);
 #pragma unroll
@@ -190,8 +192,9 @@ __global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __re
         }                                                                                      \
     } while (0)
 
-int launch_ln_bwd_add(const resid_t* x, const float* dln, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s) {
-    DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_add_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, dx, dxh, M, d));
+int launch_ln_bwd_add(const resid_t* x, const float* dln, int parts, int64_t part_stride, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s) {
+    GRIP_REQUIRE(parts >= 1 && part_stride % 4 == 0, "ln_bwd_add: bad partial layout (parts=%d stride=%lld)", parts, (long long)part_stride);
+    DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_add_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, dx, dxh, M, d, parts, (size_t)(part_stride / 4)));
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

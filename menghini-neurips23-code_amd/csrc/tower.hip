@@ -174,7 +174,8 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     std::vector<half_t*> qkv_l, att_l, hpre_l;
     // backward scratch
     float* dx = nullptr;
-    float* dln = nullptr;
+    float* dln = nullptr;      // [max(ks_fc, ks_in)][Mp, d] f32 split-K partials of the EPI_F32 input-gradient GEMMs
+    int ks_fc = 1, ks_in = 1;  // their split factors (gemm_pick_ksplit)
     half_t* dxh = nullptr;
     half_t* dh = nullptr;
     half_t* dqkv = nullptr;
@@ -258,7 +259,10 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
             w.hpre_l[(size_t)i] = (half_t*)take(w.Mp * 4 * d * 2);
         }
         w.dx = (float*)take(w.Mp * d * 4);
-        w.dln = (float*)take(w.Mp * d * 4);
+        // split-K partial buffers of the two EPI_F32 input-gradient GEMMs of a block (summed by ln_bwd_add)
+        w.ks_fc = gemm_pick_ksplit((int)w.M, d, 4 * d);
+        w.ks_in = gemm_pick_ksplit((int)w.M, d, 3 * d);
+        w.dln = (float*)take(w.Mp * d * 4 * (size_t)(w.ks_fc > w.ks_in ? w.ks_fc : w.ks_in));
         w.dxh = (half_t*)take(w.Mp * d * 2);
         w.dh = (half_t*)take(w.Mp * 4 * d * 2);
         w.dqkv = (half_t*)take(w.Mp * 3 * d * 2);
@@ -517,6 +521,17 @@ extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int
     if (variant == 7) { a.f32 = 1; a.variant = 0; }   // f32 operands: the exact-mode kernel (gemm_f32.hip)
     return launch_gemm(epi, a, (hipStream_t)stream);
 }
+// Split-K EPI_F32 product: out holds `ksplit` partial [M, N] buffers `split_stride` floats apart (ksplit = 0: the launcher's
+// own choice, returned through *ksplit_used); their sum in index order is what ln_bwd_add consumes.
+extern "C" int grip_debug_gemm_splitk(const void* A, const void* W, int M, int N, int K, float* out, int ksplit, int64_t split_stride, int* ksplit_used,
+                                      int m_pad, void* stream) {
+    GemmArgs a{};
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.out = out; a.ldc = N;
+    a.ksplit = ksplit ? ksplit : gemm_pick_ksplit(M, N, K);
+    a.split_stride = split_stride;
+    if (ksplit_used) *ksplit_used = a.ksplit;
+    return launch_gemm(EPI_F32, a, (hipStream_t)stream);
+}
 extern "C" int grip_debug_gemm_ln(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid, void* out, void* out2,
                                   float* stat_part, const float* rowstat, const float* colsum, int m_pad, int variant, void* stream) {
     GemmArgs a{};
@@ -548,6 +563,7 @@ static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, hipStrea
     const int d = t->D.width, H = t->D.heads;
     const half_t* W = t->w16;
     const float* F = t->w32;
+    const int64_t part = (int64_t)w.Mp * d;       // floats between split-K partial buffers in w.dln
     for (int l = t->D.layers - 1; l >= 0; --l) {
         const LayerW& lw = t->L.layer[(size_t)l];
         GemmArgs a{};
@@ -556,16 +572,18 @@ static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, hipStrea
         RUN(launch_gemm(EPI_GELUGRAD_F16, a, s));
         a = GemmArgs{};
         a.A = w.dh; a.W = W + lw.fc_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.out = w.dln; a.ldc = d;
+        a.ksplit = w.ks_fc; a.split_stride = part;
         RUN(launch_gemm(EPI_F32, a, s));
-        RUN(launch_ln_bwd_add(w.x_mid[(size_t)l], w.dln, F + lw.ln2_g, w.dx, w.dxh, w.M, d, s));
+        RUN(launch_ln_bwd_add(w.x_mid[(size_t)l], w.dln, w.ks_fc, part, F + lw.ln2_g, w.dx, w.dxh, w.M, d, s));
         a = GemmArgs{};
         a.A = w.dxh; a.W = W + lw.out_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.out = w.datt; a.ldc = d;
         RUN(launch_gemm(EPI_F16, a, s));
         RUN(launch_attention_bwd(w.qkv_l[(size_t)l], w.att_l[(size_t)l], w.datt, w.dqkv, w.batch, w.S, H, causal, s));
         a = GemmArgs{};
         a.A = w.dqkv; a.W = W + lw.in_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 3 * d; a.out = w.dln; a.ldc = d;
+        a.ksplit = w.ks_in; a.split_stride = part;
         RUN(launch_gemm(EPI_F32, a, s));
-        RUN(launch_ln_bwd_add(w.x_in[(size_t)l], w.dln, F + lw.ln1_g, w.dx, w.dxh, w.M, d, s));
+        RUN(launch_ln_bwd_add(w.x_in[(size_t)l], w.dln, w.ks_in, part, F + lw.ln1_g, w.dx, w.dxh, w.M, d, s));
     }
     return GRIP_OK;
 }

@@ -146,6 +146,36 @@ def test_cosine_head_matches_torch():
     assert (am_p.long() == probs.argmax(1)).all()
 
 
+@pytest.mark.parametrize("M,N,K,ksplit", [(2142, 512, 2048, 0), (2142, 512, 1536, 0), (3408, 768, 3072, 0), (100, 128, 512, 2), (777, 256, 1536, 8),
+                                          (40000, 768, 3072, 0)])
+def test_split_k_input_gradient_gemm(M, N, K, ksplit):
+    """The EPI_F32 input-gradient products of the prompt steps (few output tiles, long K) are split over K: each workgroup writes
+    a partial product; the partials, summed in index order (what ln_bwd_add does), equal the product."""
+    import ctypes
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    Mp = (M + 255) // 256 * 256
+    A = torch.randn(Mp, K, device="cuda", generator=g).half()
+    A[M:] = float("nan")
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    used = ctypes.c_int(0)
+    out = torch.full((8, Mp, N), float("nan"), device="cuda")
+    native.check(lib.grip_debug_gemm_splitk(_p(A), _p(W), M, N, K, _p(out), ksplit, Mp * N, ctypes.addressof(used), Mp, _stream()))
+    torch.cuda.synchronize()
+    ks = used.value
+    assert ks == ksplit or (ksplit == 0 and 1 <= ks <= 8)
+    if ksplit == 0 and M < 4000:
+        assert ks > 1, "the prompt-step shapes are the ones the split exists for"
+    if M >= 40000:
+        assert ks == 1
+    assert torch.isnan(out[ks:]).all() and torch.isnan(out[:ks, M:]).all(), "wrote outside its partial buffers / rows"
+    kp = K // ks
+    for p in range(ks):
+        ref = A[:M, p * kp:(p + 1) * kp].float() @ W[:, p * kp:(p + 1) * kp].float().t()
+        torch.testing.assert_close(out[p, :M], ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out[:ks, :M].sum(0), A[:M].float() @ W.float().t(), rtol=1e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("M,d,N2", [(200, 256, 768), (3408, 768, 2304), (66000, 768, 3072), (35000, 1024, 1024), (77 * 21, 512, 1536)])
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
 def test_layernorm_folded_into_gemm(M, d, N2, variant):
