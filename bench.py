@@ -101,6 +101,7 @@ class Loop:
         self.model = TextPrefixModel(prefix, enc, self.classes, device=device)
         self.opt = torch.optim.SGD([self.model.prefix], lr=0.1, weight_decay=0.1)
         self.graphed = steps.GraphedCoopStep(self.model, self.m, self.opt) if args.graph else None
+        self.graphed_f = steps.GraphedCoopFeatureStep(self.model, self.m, self.opt) if args.graph else None
         self.t_pl = self.t_tr = 0.0
         self.m_selected = 0
         self.train_steps = 0
@@ -132,18 +133,34 @@ class Loop:
         my_img = torch.from_numpy(img[mine] - lo).long().to(self.device)
         my_lab = torch.from_numpy(cls[mine]).to(self.device)
         n_steps = math.ceil(len(img) / (a.batch * self.ws)) if len(img) else 0
-        for t in range(n_steps):
-            if len(my_img):
-                idx = (torch.arange(a.batch, device=self.device) + t * a.batch) % len(my_img)
-                x, y = self.pool[my_img[idx]], my_lab[idx]
-                w = torch.full((a.batch,), 1.0 / a.batch, device=self.device)
-            else:   # no selected image lives in this rank's shard: same work, zero weight (it still joins the all-reduce)
-                x, y = self.pool[: a.batch], torch.zeros(a.batch, dtype=torch.int32, device=self.device)
-                w = torch.zeros(a.batch, device=self.device)
-            if self.graphed is not None:
-                self.graphed(x, y, w)
-            else:
-                steps.coop_step(self.model, self.m, x, y, w, self.opt)
+        # the batch index of every step of this pass at once (one gather per look-ahead group instead of six tiny launches per step)
+        own = len(my_img) > 0
+        if own:
+            order = my_img[torch.arange(n_steps * a.batch, device=self.device) % len(my_img)]
+            labels = my_lab[torch.arange(n_steps * a.batch, device=self.device) % len(my_img)]
+            w_row = torch.full((a.batch,), 1.0 / a.batch, device=self.device)
+        else:   # no selected image lives in this rank's shard: same work, zero weight (it still joins the all-reduce)
+            order = torch.arange(a.batch, device=self.device).repeat(n_steps)
+            labels = torch.zeros(n_steps * a.batch, dtype=torch.int32, device=self.device)
+            w_row = torch.zeros(a.batch, device=self.device)
+
+        def batches():
+            for t in range(n_steps):
+                sl = slice(t * a.batch, (t + 1) * a.batch)
+                yield self.pool[order[sl]], labels[sl], w_row
+
+        if a.lookahead > 1:     # frozen image tower encoded `lookahead` steps at a time (steps.lookahead_image_features)
+            for f, y, w in steps.lookahead_image_features(self.m, batches(), a.lookahead):
+                if self.graphed_f is not None:
+                    self.graphed_f(f, y, w)
+                else:
+                    steps.coop_step(self.model, self.m, None, y, w, self.opt, image_features=f)
+        else:
+            for x, y, w in batches():
+                if self.graphed is not None:
+                    self.graphed(x, y, w)
+                else:
+                    steps.coop_step(self.model, self.m, x, y, w, self.opt)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         self.t_pl += t1 - t0
@@ -370,6 +387,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=64, help="images of the R-mode CPU baseline (BASELINE.md section 3: >= 64)")
     ap.add_argument("--cpu-text-reps", type=int, default=6, help="how many of them time the full clip_model(image, text) call (the per-image text re-encode)")
     ap.add_argument("--cpu-full", action="store_true", help="time the literal R-mode loop on every sampled image (~6 s each)")
+    ap.add_argument("--lookahead", type=int, default=13,
+                    help="CoOp steps whose frozen image-tower forward is batched into one encode (steps.lookahead_image_features); 1 = encode inside every step")
     ap.add_argument("--graph", type=int, default=1, choices=(0, 1),
                     help="1: the CoOp step's forward + backward replayed from a HIP graph captured once (steps.GraphedCoopStep); 0: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -443,6 +462,8 @@ def main():
                    "encode_chunk": args.chunk, "encode_streams": args.streams, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
                    "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps),
                    "text_positions_encoded": seq, "prompt_step_hip_graph": bool(args.graph),
+                   "train_image_lookahead": f"{args.lookahead} steps: the frozen image tower encodes the batches of {args.lookahead} consecutive prompt steps in one forward "
+                                            "(every image is encoded every time a step uses it; nothing is cached)" if args.lookahead > 1 else "1 (encode inside every step)",
                    "last_block_rows_only": f_img_x != F_IMG,
                    "train_sharding": "each rank steps on the selected images of its OWN shard (zero-weight rows where it owns none), batch 16 per rank; "
                                      "prompt gradients are mean-all-reduced every step -- not one global batch split over ranks",

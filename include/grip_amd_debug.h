@@ -23,7 +23,7 @@ int grip_debug_gemm_ln(int epi, const void* A, const void* W, int M, int N, int 
 /* Split-K product (the input-gradient GEMMs of the prompt steps): out = ksplit partial [M, N] f32 buffers, split_stride floats apart,
  * partial p = A[:, Kp] W[:, Kp]^T over the p-th K range.  ksplit = 0: the launcher's own choice; *ksplit_used receives the factor. */
 int grip_debug_gemm_splitk(const void* A, const void* W, int M, int N, int K, float* out, int ksplit, int64_t split_stride, int* ksplit_used,
-                           int m_pad, void* stream);
+                           int m_pad, int variant, void* stream);
 /* Wg = f16(gamma o W) [N, K], colsum[n] = sum_k Wg[n][k], bias_out = bias + W beta; then, if stat_part != NULL,
  * rowstat [M, 2] = (mean, rstd) from the [M, parts, 2] partial sums over rows of width d. */
 int grip_debug_ln_fold(const void* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* colsum, float* bias_out,

@@ -209,6 +209,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[RO
         epilogue_rows_impl<EPI, ROWFRAGS, true, PF, PRE>(g, acc, slab, row0, col0, lane, pre);
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // WMF = 16-row fragments per wave along M: 4 -> 128x128 block tile, 2 -> 64x128 (small-M problems such as the
 // training batches, where 128-row tiles leave half of the 256 CUs without a workgroup).
 template <int EPI, int WMF>
@@ -305,6 +310,106 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small-M problems with FEW output tiles (the prompt-step GEMMs: M = 2 142 text rows or 3 408 image rows, N = d: 136-324
+// tiles of 64x128 on 256 CUs): one workgroup per CU at most, so the two-stage loop above keeps ONE 24 KiB tile in flight per
+// CU and runs at (tile bytes) / (L2 latency) = 35 B/ns per CU, a quarter of what a CU can pull.  Same tile, same LDS byte
+// layout, same fragments; the stages form a ring of NST tiles fed NST-1 tiles ahead and retired with counted waits
+// (vmcnt = loads of the tiles younger than the one about to be multiplied), one raw barrier per K tile.
+template <int EPI, int NST>
+__global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int WMF = 2;
+    constexpr int BMT = 64;
+    constexpr int STAGE = (BMT + BN) * BK;       // halfs: 24 KiB
+    constexpr int G = 2 + 4;                     // global_load_lds per wave per tile
+    extern __shared__ __attribute__((aligned(16))) half_t lds2[];
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BMT, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const size_t K = (size_t)g.K;
+    const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + wave * 16 + srow) * K + schunk * 8;
+    const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * 32 + srow) * K + schunk * 8;
+
+    auto stage = [&](int buf, int kt) {
+        half_t* abase = lds2 + buf * STAGE + wave * 16 * BK;
+        half_t* bbase = lds2 + buf * STAGE + BMT * BK + wave * 32 * BK;
+        const half_t* as = a_src + (size_t)kt * BK;
+        const half_t* ws = w_src + (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 8 * K), (AS3 void*)(abase + i * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 8 * K), (AS3 void*)(bbase + i * 8 * BK), 16, 0, 0);
+    };
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
+        a_off[kk] = (wr * WMF * 16 + frow) * BK + chunk * 8;
+        b_off[kk] = BMT * BK + (wc * 64 + frow) * BK + chunk * 8;
+    }
+
+    f32x4 acc[WMF][4];
+    init_acc<EPI, WMF>(g, acc, n0 + wc * 64, lane);
+
+    int nk = g.K / BK, kt0 = 0;                   // nk >= NST - 1 (launcher)
+    if constexpr (EPI == EPI_F32) {
+        if (gridDim.y > 1) {                      // split-K: k tiles [kt0, kt0 + nk) into partial buffer blockIdx.y
+            nk /= (int)gridDim.y;
+            kt0 = (int)blockIdx.y * nk;
+            g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) stage(t, kt0 + t);
+    int buf = 0, nbuf = NST - 1;                  // slot of tile kt, slot the tile kt + NST - 1 goes to
+    for (int kt = 0; kt < nk; ++kt) {
+        const int younger = nk - 1 - kt;          // tiles issued after tile kt that may still be in flight (capped at NST - 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (younger >= NST - 2) wait_vmcnt<(NST - 2) * G>();
+        else if (NST > 3 && younger == 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();             // tile kt landed for every wave; the slot of tile kt-1 has been read by every wave
+        if (kt + NST - 1 < nk) stage(nbuf, kt0 + kt + NST - 1);
+        const half_t* st = lds2 + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 af[WMF], bf[4];
+#pragma unroll
+            for (int i = 0; i < WMF; ++i) af[i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
+
+    __syncthreads();   // every wave is done with the ring: reuse it as epilogue slabs
+    epilogue_rows<EPI, WMF>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Large-problem variants: BM x BN x 32 block tile, one wave per 128x64 sub-tile (8x4 fragments, 128
 // accumulator registers, 32 MFMA per 12 ds_read_b128 per K tile):
 //     256x256: 8 waves, 4-stage ring (128 KiB LDS, one workgroup per CU), 128 FLOP per staged byte;
@@ -319,10 +424,6 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
 // T[(row >> 2) & 3], T = {0,2,3,1}, on the SOURCE address and on the read: ds_read_b128 conflict-free.
 #define BK2 32
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <int EPI, int BMT, int BNT, int NSTAGE>
 __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_kernel(GemmArgs g, int tiles_m, int tiles_n) {
@@ -989,18 +1090,52 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
 
 // variant: 0 = choose, 1 = 128x128x64 (2-stage), 2 = 256x256x32 (4-stage ring), 3 = 256x128x32 (3-stage ring), 4 = 64x128x64 (2-stage),
 //          5 = 256x256x64 (2-stage, whole-line DMA), 6 = the same, persistent
-// Split-K factor for an EPI_F32 product whose output has too few 64x128 tiles to fill 256 CUs x 3 workgroups while K is
-// long (the input-gradient GEMMs of the prompt steps: 136 tiles x 32 k-steps at M = 2 142, N = 512, K = 2 048): the
-// largest factor that keeps >= 4 k-steps per workgroup and <= 768 workgroups.
+// Split-K factor for an EPI_F32 product whose output has too few 64x128 tiles while K is long (the input-gradient GEMMs of
+// the prompt steps: 136 tiles x 32 k-steps at M = 2 142, N = 512, K = 2 048): the SMALLEST factor that puts a workgroup on every
+// CU (>= 256 workgroups) with >= 4 k-steps each, and at least 2 below 512 tiles.  Measured (tools/small_gemm_bench.py,
+// SWEEP=1): text 15.5 us unsplit -> 11.7 at 2 = 11.7 at 4; image (324 tiles) 30.7 -> 24.7 at 2, 26.7 at 4 -- beyond one
+// workgroup per CU more partials only add traffic for the consumer (ln_bwd_add reads every partial).
 int gemm_pick_ksplit(int M, int N, int K) {
-    static const int off = getenv("GRIP_GEMM_KSPLIT") ? atoi(getenv("GRIP_GEMM_KSPLIT")) : -1;   // developer A/B: 1 disables
-    if (off == 1) return 1;
+    static const int force = getenv("GRIP_GEMM_KSPLIT") ? atoi(getenv("GRIP_GEMM_KSPLIT")) : 0;   // developer A/B: 1 disables, n forces
     const int64_t tiles = (int64_t)((M + 63) / 64) * (N / BN);
     const int nk = K / BK;
-    int best = 1;
+    if (force >= 1) return nk % force == 0 ? force : 1;
+    if (tiles >= 512) return 1;
     for (int f : {2, 3, 4, 6, 8})
-        if (nk % f == 0 && nk / f >= 4 && tiles * f <= 768) best = f;
-    return best;
+        if (nk % f == 0 && nk / f >= 4 && tiles * f >= 256) return f;
+    return 1;
+}
+
+static int launch_ring(int epi, const GemmArgs& a, int nst, dim3 grid, hipStream_t s) {
+    const int tiles_m = (a.M + 63) / 64, tiles_n = a.N / BN;
+    const size_t lds = (size_t)nst * (64 + BN) * BK * 2;
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + BN) * BK * 2)); \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 + BN) * BK * 2)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        if (nst == 3) hipLaunchKernelGGL((gemm_ring_kernel<E, 3>), grid, dim3(256), lds, s, a, tiles_m, tiles_n);           \
+        else hipLaunchKernelGGL((gemm_ring_kernel<E, 4>), grid, dim3(256), lds, s, a, tiles_m, tiles_n);                    \
+    } break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
+        GRIP_GEMM_CASE(EPI_F16)
+        GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
+        GRIP_GEMM_CASE(EPI_F32_SCALE)
+        GRIP_GEMM_CASE(EPI_LNFOLD_F16)
+        GRIP_GEMM_CASE(EPI_LNFOLD_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_STATS)
+        default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
 }
 
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
@@ -1062,6 +1197,16 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
     const int bmt = variant == 4 ? 64 : 128;
     const int tiles_m = (a.M + bmt - 1) / bmt, tiles_n = a.N / BN;
     dim3 grid(tiles_m * tiles_n, ksplit), block(256);
+    if (variant == 4) {
+        // ring depth by workgroups per CU: <= 1 -> four stages (96 KiB), <= 2 -> three (72 KiB, two per CU); beyond that three
+        // co-resident two-stage workgroups already keep three tiles in flight per CU
+        static const int force = getenv("GRIP_GEMM_RING") ? atoi(getenv("GRIP_GEMM_RING")) : -1;    // developer A/B: 0 (off), 3, 4
+        const int64_t wgs = (int64_t)grid.x * ksplit;
+        const int nk = a.K / BK / ksplit;
+        int nst = force >= 0 ? force : (wgs <= 256 ? 4 : (wgs <= 512 ? 3 : 0));
+        if (nst && nk < nst - 1) nst = 0;
+        if (nst) return launch_ring(epi, a, nst, grid, s);
+    }
 #define GRIP_GEMM_CASE(E)                                                                                  \
     case E:                                                                                                \
         if (variant == 4) hipLaunchKernelGGL((gemm_f16_kernel<E, 2>), grid, block, 0, s, a, tiles_m, tiles_n); \

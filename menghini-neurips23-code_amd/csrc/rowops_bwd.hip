@@ -120,32 +120,33 @@ __global__ __launch_bounds__(256) void vit_prefix_grad_kernel(const float* __res
 }
 
 // Textual prompt slice: grad_prefix[pc][p] = inv_scale * sum_{c in group} dx[c*T + 1 + p]
+// One wave per (prompt token, 256-float slice of the row): a shared prompt sums C rows in class order, sixteen loads in flight.
 __global__ __launch_bounds__(256) void text_prefix_grad_kernel(const float* __restrict__ dx, const float* __restrict__ scale, float* __restrict__ grad,
                                                                int C, int T, int P, int prefix_classes, int d) {
     const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (idx >= prefix_classes * P) return;
-    const int pc = idx / P, p = idx - pc * P;
     const int d4 = d >> 2;
+    const int nf = (d4 + 63) >> 6;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int idx = w / nf, f = (w - idx * nf) * 64 + lane;
+    if (idx >= prefix_classes * P || f >= d4) return;
+    const int pc = idx / P, p = idx - pc * P;
     const float inv = scale[1];
-    for (int f = lane; f < d4; f += 64) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (prefix_classes == 1) {
-            // eight rows in flight per trip, added in class order (the sum is the same sequence of f32 adds as a plain loop)
-            int c = 0;
-            for (; c + 8 <= C; c += 8) {
-                f32x4 r[8];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (prefix_classes == 1) {
+        // added in class order (the sum is the same sequence of f32 adds as a plain loop)
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {
+            f32x4 r[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) r[u] = ((const f32x4*)(dx + ((size_t)(c + u) * T + 1 + p) * d))[f];
+            for (int u = 0; u < 16; ++u) r[u] = ((const f32x4*)(dx + ((size_t)(c + u) * T + 1 + p) * d))[f];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += r[u];
-            }
-            for (; c < C; ++c) acc += ((const f32x4*)(dx + ((size_t)c * T + 1 + p) * d))[f];
-        } else {
-            acc = ((const f32x4*)(dx + ((size_t)pc * T + 1 + p) * d))[f];
+            for (int u = 0; u < 16; ++u) acc += r[u];
         }
-        ((f32x4*)(grad + (size_t)idx * d))[f] = acc * inv;
+        for (; c < C; ++c) acc += ((const f32x4*)(dx + ((size_t)c * T + 1 + p) * d))[f];
+    } else {
+        acc = ((const f32x4*)(dx + ((size_t)pc * T + 1 + p) * d))[f];
     }
+    ((f32x4*)(grad + (size_t)idx * d))[f] = acc * inv;
 }
 
 // Dynamic loss scale: scale[0] = 2^k with amax(g) * 2^k in [32, 64), scale[1] = 2^-k; g16 = f16(g * scale).
@@ -155,7 +156,12 @@ __global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __re
     __shared__ float red[16];
     __shared__ float sc;
     float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
+    const int n4 = (n & 3) == 0 ? n >> 2 : 0;        // 16-byte path when the length allows (embedding blocks always do)
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const f32x4 v = ((const f32x4*)g)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -175,7 +181,11 @@ __global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __re
     }
     __syncthreads();
     const float s = sc;
-    for (int i = threadIdx.x; i < n; i += 1024) g16[i] = (half_t)(g[i] * s);
+    for (int i = threadIdx.x; i < n4; i += 1024) {
+        const f32x4 v = ((const f32x4*)g)[i] * s;
+        ((half4*)g16)[i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < n; i += 1024) g16[i] = (half_t)(g[i] * s);
 }
 
 #define DISPATCH_NV_B(d, CALL)                                                                 \
@@ -210,7 +220,8 @@ int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* ga
     return GRIP_OK;
 }
 int launch_text_prefix_grad(const float* dx, const float* scale, float* grad, int C, int T, int P, int prefix_classes, int d, hipStream_t s) {
-    hipLaunchKernelGGL(text_prefix_grad_kernel, dim3((prefix_classes * P + 3) / 4), dim3(256), 0, s, dx, scale, grad, C, T, P, prefix_classes, d);
+    const int waves = prefix_classes * P * ((d / 4 + 63) / 64);
+    hipLaunchKernelGGL(text_prefix_grad_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, dx, scale, grad, C, T, P, prefix_classes, d);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -524,8 +524,9 @@ extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int
 // Split-K EPI_F32 product: out holds `ksplit` partial [M, N] buffers `split_stride` floats apart (ksplit = 0: the launcher's
 // own choice, returned through *ksplit_used); their sum in index order is what ln_bwd_add consumes.
 extern "C" int grip_debug_gemm_splitk(const void* A, const void* W, int M, int N, int K, float* out, int ksplit, int64_t split_stride, int* ksplit_used,
-                                      int m_pad, void* stream) {
+                                      int m_pad, int variant, void* stream) {
     GemmArgs a{};
+    a.variant = variant;
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.out = out; a.ldc = N;
     a.ksplit = ksplit ? ksplit : gemm_pick_ksplit(M, N, K);
     a.split_stride = split_stride;

@@ -208,8 +208,15 @@ class Tower:
         if not self._finalized:
             self.finalize()
         assert self.kind == 1
-        ids = token_ids.to(device=self.device, dtype=torch.int32).contiguous()
-        eot = ids.argmax(dim=-1).to(torch.int32).contiguous()
+        # int32 ids and EOT row indices are kept on the token tensor (keyed by its version counter: an in-place edit recomputes
+        # them) -- a prompt step would otherwise spend three tiny launches per forward re-deriving the same indices
+        memo = getattr(token_ids, "_grip_ids", None)
+        if memo is not None and memo[0] == token_ids._version and memo[1].device == self.device:
+            ids, eot = memo[1], memo[2]
+        else:
+            ids = token_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            eot = ids.argmax(dim=-1).to(torch.int32).contiguous()
+            token_ids._grip_ids = (token_ids._version, ids, eot)
         C = ids.shape[0]
         if seq_len is None:
             seq_len = min(int(eot.max().item()) + 1, self.seq0) if self.truncate_text_at_eot else 0

@@ -185,6 +185,57 @@ class GraphedCoopStep(GraphedStep):
         return coop_step(self.model, self.clip_model, images, labels, row_weight, self.optimizer)
 
 
+class GraphedCoopFeatureStep(GraphedStep):
+    """coop_step on image features that were encoded ahead (lookahead_image_features): the text tower's forward + backward, the
+    cosine head and the loss, replayed from a HIP graph; the static input is the feature block [B, embed_dim]."""
+
+    def __init__(self, model, clip_model, optimizer):
+        super().__init__(optimizer)
+        self.model, self.clip_model = model, clip_model
+        self.scale = clip_model.logit_scale.exp().item()
+
+    def params(self):
+        return [self.model.prefix]
+
+    def shape_key(self, feats):
+        return (tuple(feats.shape), feats.dtype, tuple(self.model.classes))
+
+    def forward_logits(self):
+        return CosineHeadFn.apply(self.x, self.model(self.model.classes), self.scale)
+
+    def eager(self, feats, labels, row_weight):
+        return coop_step(self.model, self.clip_model, None, labels, row_weight, self.optimizer, image_features=feats)
+
+
+def lookahead_image_features(clip_model, batches, group=8):
+    """The frozen image tower of a textual-prompt epoch, run `group` batches ahead: the image features of a step do not depend
+    on the prompt being trained, so the batches of `group` consecutive steps are encoded in ONE inference forward (group x B x S
+    rows feed the persistent 256x256 GEMMs at the pool-encode rate; a 16-image forward leaves them a quarter full) and each
+    step receives its slice.  Every image is still encoded every time a step uses it (nothing is cached across steps or epochs),
+    and the engine's forward is chunk-independent, so the features are bit-identical to a per-step encode.
+
+    `batches` yields tuples whose first element is the image batch [B, 3, R, R] (any further elements are passed through);
+    yields (features [B, embed_dim], *rest) in the same order."""
+    pending = []
+
+    def flush():
+        with torch.no_grad():
+            feats = clip_model.encode_image(torch.cat([b[0] for b in pending]))
+        at = 0
+        for b in pending:
+            n = b[0].shape[0]
+            yield (feats[at:at + n],) + tuple(b[1:])
+            at += n
+        pending.clear()
+
+    for b in batches:
+        pending.append(b)
+        if len(pending) == group:
+            yield from flush()
+    if pending:
+        yield from flush()
+
+
 class GraphedVptStep(GraphedStep):
     """vpt_step (visual prompt: image tower forward + backward; text features fixed for the epoch) replayed from a HIP graph."""
 

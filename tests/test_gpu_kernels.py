@@ -160,7 +160,7 @@ def test_split_k_input_gradient_gemm(M, N, K, ksplit):
     W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
     used = ctypes.c_int(0)
     out = torch.full((8, Mp, N), float("nan"), device="cuda")
-    native.check(lib.grip_debug_gemm_splitk(_p(A), _p(W), M, N, K, _p(out), ksplit, Mp * N, ctypes.addressof(used), Mp, _stream()))
+    native.check(lib.grip_debug_gemm_splitk(_p(A), _p(W), M, N, K, _p(out), ksplit, Mp * N, ctypes.addressof(used), Mp, 0, _stream()))
     torch.cuda.synchronize()
     ks = used.value
     assert ks == ksplit or (ksplit == 0 and 1 <= ks <= 8)
