@@ -37,7 +37,7 @@ typedef enum {
 const char* grip_last_error(void);
 /* ABI version of this header; the host layer refuses a library that reports another one. */
 int grip_abi_version(void);
-#define GRIP_ABI_VERSION 3
+#define GRIP_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------------------------
  * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
@@ -124,10 +124,22 @@ int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* 
  *              read, so positions after the last EOT cannot influence any output: the result is the same, the work
  *              shrinks by seq0 / seq_len (CoOp prompts are ~20 of 77 tokens).
  *   out_emb    [n_class, embed_dim] f32
+ *   flags      GRIP_FWD_TRAIN: keep the activations grip_text_backward_prefix needs (the `train` argument of ABI <= 3).
+ *              GRIP_FWD_SHARED_PREFIX: the caller vouches that token_ids[c][0 .. n_prefix] is the same for every class
+ *              (SOT + the context placeholders of CustomTextEncoder, :63-74) and eot_index[c] > n_prefix.  With one shared
+ *              context (prefix_classes == 1) those 1 + n_prefix positions then carry identical activations for every class
+ *              in every layer -- same inputs, same positions, causal mask -- so the engine encodes them ONCE and keeps
+ *              only the class-specific positions per class (1 + n_prefix + n_class * (seq_len - 1 - n_prefix) rows
+ *              instead of n_class * seq_len: 425 instead of 2 142 for 102 classes x 21 positions, 16 context tokens); the
+ *              class positions attend to the shared keys and their own, and the backward adds every class's share of
+ *              the shared keys' gradient in class order.  Embeddings and prompt gradient are the same function of the
+ *              inputs; ignored (plain layout) when prefix_classes != 1, n_prefix == 0 or dims.precision == 1.
  */
+#define GRIP_FWD_TRAIN 1
+#define GRIP_FWD_SHARED_PREFIX 2
 int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
                       int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
-                      void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream);
+                      void* workspace, size_t workspace_bytes, int flags, uint64_t* generation, void* stream);
 
 /* grad_emb [n_class, embed_dim] -> grad_prefix [prefix_classes, n_prefix, width] (summed over classes
  * when prefix_classes == 1). */

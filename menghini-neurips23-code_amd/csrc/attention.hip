@@ -92,7 +92,7 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
 }
 
 template <int KVC, bool CAUSAL, int ATT_NW>
-__global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H) {
+__global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int S, int H, int Ps) {
     constexpr int SP = KVC * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Ks = (half_t*)smem;
@@ -102,26 +102,30 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __r
     const int D = H * 64;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const size_t ld = (size_t)3 * D;
-    const half_t* base = qkv + (size_t)b * S * ld + h * 64;
+    const half_t* base = qkv + h * 64;
     const int li = lane & 15, lg = lane >> 4;
     const int n_qt = (S + 15) >> 4;
+    // shared-prefix layout: the shared rows are produced by sequence 0's workgroups only
+    const int q_min = (Ps > 0 && b > 0) ? Ps : 0;
+    const int qt0 = q_min >> 4;
 
     // Q fragments of this wave's first tile go out before the K/V staging so their latency hides behind it;
     // inside the loop the NEXT tile's Q is fetched while the current one is being processed.
     auto load_q = [&](int qt, half8 (&qf)[2]) {
         const int qrow = qt * 16 + li;
         const int qr = qrow < S ? qrow : S - 1;
+        const half_t* qp = base + seq_row(b, qr, S, Ps) * ld;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const half8*)(base + qr * ld + (kk * 4 + lg) * 8);
+        for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const half8*)(qp + (kk * 4 + lg) * 8);
     };
     half8 q_next[2];
-    load_q(wave < n_qt ? wave : 0, q_next);
+    load_q(qt0 + wave < n_qt ? qt0 + wave : 0, q_next);
 
     // K: [kv][64] rows, 16-byte chunk index XOR (kv & 7).
     for (int idx = tid; idx < SP * 8; idx += ATT_NW * 64) {
         const int row = idx >> 3, chunk = idx & 7;
         half8 kv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < S) kv = *(const half8*)(base + row * ld + D + chunk * 8);
+        if (row < S) kv = *(const half8*)(base + seq_row(b, row, S, Ps) * ld + D + chunk * 8);
         *(half8*)(Ks + row * 64 + ((chunk ^ (row & 7)) * 8)) = kv;
     }
     // V image (vt_index).  A lane takes a PAIR of keys (2r, 2r+1) and one 8-wide slice of the head dim and writes
@@ -132,19 +136,20 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __r
         const int r0 = 2 * rp;
         if (r0 >= SP) continue;
         half8 v0 = {0, 0, 0, 0, 0, 0, 0, 0}, v1 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (r0 < S) v0 = *(const half8*)(base + r0 * ld + 2 * D + chunk * 8);
-        if (r0 + 1 < S) v1 = *(const half8*)(base + (r0 + 1) * ld + 2 * D + chunk * 8);
+        if (r0 < S) v0 = *(const half8*)(base + seq_row(b, r0, S, Ps) * ld + 2 * D + chunk * 8);
+        if (r0 + 1 < S) v1 = *(const half8*)(base + seq_row(b, r0 + 1, S, Ps) * ld + 2 * D + chunk * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) *(half2v*)(Vt + vt_index(r0, chunk * 8 + j)) = (half2v){v0[j], v1[j]};
     }
     __syncthreads();
 
-    for (int qt = wave; qt < n_qt; qt += ATT_NW) {
+    for (int qt = qt0 + wave; qt < n_qt; qt += ATT_NW) {
         asm volatile("" ::: "memory");  // keep the K/V fragment reads inside the tile loop (hoisting them costs >100 VGPRs)
         const int qrow = qt * 16 + li;
         half8 qf[2] = {q_next[0], q_next[1]};
         if (qt + ATT_NW < n_qt) load_q(qt + ATT_NW, q_next);
-        attn_tile<KVC, CAUSAL>(Ks, Vt, qf, qrow, S, out + ((size_t)b * S + qrow) * D + h * 64, lane);
+        const int qs = qrow < S ? qrow : S - 1;
+        attn_tile<KVC, CAUSAL>(Ks, Vt, qf, qrow, S, out + seq_row(b, qs, S, Ps) * D + h * 64, lane, qrow >= q_min);
     }
 }
 
@@ -293,7 +298,7 @@ static int launch_pipe(const half_t* qkv, half_t* out, int B, int S, int H, hipS
 }
 
 template <int KVC, bool CAUSAL, int ATT_NW>
-static int launch_one(const half_t* qkv, half_t* out, int B, int S, int H, hipStream_t s) {
+static int launch_one(const half_t* qkv, half_t* out, int B, int S, int H, hipStream_t s, int Ps) {
     constexpr int SP = KVC * 32;
     constexpr size_t lds = (size_t)2 * SP * 64 * 2;
     static bool configured = false;
@@ -301,13 +306,14 @@ static int launch_one(const half_t* qkv, half_t* out, int B, int S, int H, hipSt
         GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<KVC, CAUSAL, ATT_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL((attn_fwd_kernel<KVC, CAUSAL, ATT_NW>), dim3(B * H), dim3(ATT_NW * 64), lds, s, qkv, out, S, H);
+    hipLaunchKernelGGL((attn_fwd_kernel<KVC, CAUSAL, ATT_NW>), dim3(B * H), dim3(ATT_NW * 64), lds, s, qkv, out, S, H, Ps);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
 
-int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s) {
+int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s, int shared_rows) {
     const int kvc = (S + 31) / 32;
+    GRIP_REQUIRE(shared_rows == 0 || (causal && shared_rows > 0 && shared_rows < S), "attention: the shared-prefix layout needs a causal mask and 0 < shared rows < S");
     GRIP_REQUIRE(S >= 1 && kvc <= 19, "attention: sequence length %d unsupported (max 608)", S);
     // exact chunk count (the kernel relies on (KVC-1)*32 < S)
     // The persistent double-buffered kernel serves the pool encode of the 197..224-token towers (16 waves fit the
@@ -319,8 +325,8 @@ int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, in
         if (kvc == 7) return launch_pipe<7, 16>(qkv, out, B, S, H, s);
     }
 #define GRIP_ATTN(N)                                                        \
-    if (kvc == N) return causal ? launch_one<N, true, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s) \
-                                : launch_one<N, false, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s);
+    if (kvc == N) return causal ? launch_one<N, true, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s, shared_rows) \
+                                : launch_one<N, false, (N >= 4 ? 8 : 4)>(qkv, out, B, S, H, s, 0);
     GRIP_ATTN(1) GRIP_ATTN(2) GRIP_ATTN(3) GRIP_ATTN(4) GRIP_ATTN(5) GRIP_ATTN(6) GRIP_ATTN(7) GRIP_ATTN(8) GRIP_ATTN(9) GRIP_ATTN(10)
     GRIP_ATTN(11) GRIP_ATTN(12) GRIP_ATTN(13) GRIP_ATTN(14) GRIP_ATTN(15) GRIP_ATTN(16) GRIP_ATTN(17) GRIP_ATTN(18) GRIP_ATTN(19)
 #undef GRIP_ATTN

@@ -18,7 +18,8 @@
 
 template <int KVC, bool CAUSAL, int NWB>
 __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ o_saved,
-                                                       const half_t* __restrict__ d_out, half_t* __restrict__ dqkv, int S, int H) {
+                                                       const half_t* __restrict__ d_out, half_t* __restrict__ dqkv, int S, int H,
+                                                       int Ps, float* __restrict__ kv_part) {
     constexpr int SP = KVC * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Ks = (half_t*)smem;          // [SP][64] swizzled rows
@@ -34,17 +35,22 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     const int D = H * 64;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const size_t ld = (size_t)3 * D;
-    const half_t* base = qkv + (size_t)b * S * ld + h * 64;
-    const half_t* obase = o_saved + (size_t)b * S * D + h * 64;
-    const half_t* dobase = d_out + (size_t)b * S * D + h * 64;
-    half_t* dbase = dqkv + (size_t)b * S * ld + h * 64;
+    // rows through seq_row (common.h): plain layout b*S + r, or the shared-prefix layout of the text tower (Ps > 0), where the
+    // shared query rows belong to sequence 0 alone (q_min) and every sequence adds its share to the shared keys' dK / dV
+    const half_t* base = qkv + h * 64;
+    const half_t* obase = o_saved + h * 64;
+    const half_t* dobase = d_out + h * 64;
+    half_t* dbase = dqkv + h * 64;
+    const int q_min = (Ps > 0 && b > 0) ? Ps : 0;
+    auto R = [&](int r) { return seq_row(b, r, S, Ps); };
 
     for (int idx = tid; idx < SP * 8; idx += NWB * 64) {
         const int row = idx >> 3, chunk = idx & 7;
         half8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
         if (row < S) {
-            kv = *(const half8*)(base + row * ld + D + chunk * 8);
-            vv = *(const half8*)(base + row * ld + 2 * D + chunk * 8);
+            const half_t* rp = base + R(row) * ld;
+            kv = *(const half8*)(rp + D + chunk * 8);
+            vv = *(const half8*)(rp + 2 * D + chunk * 8);
         }
         const int sw = (chunk ^ (row & 7)) * 8;
         *(half8*)(Ks + row * 64 + sw) = kv;
@@ -56,18 +62,19 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
 
     const int n_qt = (S + 15) >> 4;
     // ------------------------------------------------------------------ phase 1: dQ and row statistics
-    for (int qt = wave; qt < n_qt; qt += NWB) {
+    for (int qt = (q_min >> 4) + wave; qt < n_qt; qt += NWB) {
         asm volatile("" ::: "memory");
         const int qrow = qt * 16 + li;
         const int qr = qrow < S ? qrow : S - 1;
+        const size_t qg = R(qr);
         half8 qf[2], dof[2];
         float dl = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            qf[kk] = *(const half8*)(base + qr * ld + (kk * 4 + lg) * 8);
+            qf[kk] = *(const half8*)(base + qg * ld + (kk * 4 + lg) * 8);
             qf[kk] *= (half_t)0.125f;
-            dof[kk] = *(const half8*)(dobase + (size_t)qr * D + (kk * 4 + lg) * 8);
-            const half8 of = *(const half8*)(obase + (size_t)qr * D + (kk * 4 + lg) * 8);
+            dof[kk] = *(const half8*)(dobase + qg * D + (kk * 4 + lg) * 8);
+            const half8 of = *(const half8*)(obase + qg * D + (kk * 4 + lg) * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) dl += (float)dof[kk][j] * (float)of[j];
         }
@@ -134,8 +141,8 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                 dq[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, sf, dq[nf], 0, 0, 0);
             }
         }
-        if (qrow < S) {
-            half_t* op = dbase + qrow * ld + lg * 4;
+        if (qrow < S && qrow >= q_min) {
+            half_t* op = dbase + qg * ld + lg * 4;
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
                 const f32x4 v = dq[nf] * 0.125f;
@@ -148,10 +155,10 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     for (int idx = tid; idx < SP * 8; idx += NWB * 64) {
         const int row = idx >> 3, chunk = idx & 7;
         half8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, dv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < S) {
-            qv = *(const half8*)(base + row * ld + chunk * 8);
+        if (row < S && row >= q_min) {      // (queries below q_min are not this sequence's: zero rows add nothing to dK / dV)
+            qv = *(const half8*)(base + R(row) * ld + chunk * 8);
             qv *= (half_t)0.125f;
-            dv = *(const half8*)(dobase + (size_t)row * D + chunk * 8);
+            dv = *(const half8*)(dobase + R(row) * D + chunk * 8);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -184,12 +191,13 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                 const int q0 = c * 32 + half_i * 16;
                 // A operands: query rows straight from HBM (row = q0 + li)
                 const int qa = (q0 + li) < S ? (q0 + li) : S - 1;
+                const size_t qag = R(qa);
                 f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    half8 qa_f = *(const half8*)(base + qa * ld + (kk * 4 + lg) * 8);
+                    half8 qa_f = *(const half8*)(base + qag * ld + (kk * 4 + lg) * 8);
                     qa_f *= (half_t)0.125f;
-                    const half8 do_f = *(const half8*)(dobase + (size_t)qa * D + (kk * 4 + lg) * 8);
+                    const half8 do_f = *(const half8*)(dobase + qag * D + (kk * 4 + lg) * 8);
                     s_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa_f, kf[kk], s_acc, 0, 0, 0);   // S[q][kv]
                     p_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(do_f, vf[kk], p_acc, 0, 0, 0);   // dP[q][kv]
                 }
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + lg * 4 + r;
                     float p = 0.f, ds = 0.f;   // padding rows carry no statistics: keep them exactly zero
-                    if (q < S && kvrow < S && !(CAUSAL && kvrow > q)) {
+                    if (q < S && q >= q_min && kvrow < S && !(CAUSAL && kvrow > q)) {
                         p = __expf(s_acc[r] - st_m[q]) * st_il[q];
                         ds = p * (p_acc[r] - st_d[q]);
                     }
@@ -213,9 +221,18 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                 dk[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, sf, dk[nf], 0, 0, 0);   // dK^T[dh][kv]
             }
         }
-        if (kvrow < S) {
-            half_t* kp = dbase + kvrow * ld + D + lg * 4;
-            half_t* vp = dbase + kvrow * ld + 2 * D + lg * 4;
+        if (kvrow < Ps) {
+            // a shared key: this sequence's share goes to kv_part [b][key][dK | dV][D] in f32; attn_shared_kv_reduce adds the
+            // shares of all sequences in index order
+            float* pp = kv_part + (((size_t)b * Ps + kvrow) * 2) * D + h * 64 + lg * 4;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                *(f32x4*)(pp + nf * 16) = dk[nf];
+                *(f32x4*)(pp + D + nf * 16) = dv[nf];
+            }
+        } else if (kvrow < S) {
+            half_t* kp = dbase + R(kvrow) * ld + D + lg * 4;
+            half_t* vp = kp + D;
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
                 *(half4*)(kp + nf * 16) = (half4){(half_t)dk[nf][0], (half_t)dk[nf][1], (half_t)dk[nf][2], (half_t)dk[nf][3]};
@@ -225,8 +242,28 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     }
 }
 
+// dqkv[r][D + j] = f16(sum_b kv_part[b][r][j]) for the shared keys r < Ps, j over [dK | dV] (2D columns); b in index order.
+__global__ __launch_bounds__(256) void attn_shared_kv_reduce_kernel(const float* __restrict__ kv_part, half_t* __restrict__ dqkv, int B, int Ps, int D) {
+    const int n4 = Ps * 2 * D / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t stride4 = (size_t)n4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {
+        f32x4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = ((const f32x4*)kv_part)[(size_t)(b + u) * stride4 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += r[u];
+    }
+    for (; b < B; ++b) acc += ((const f32x4*)kv_part)[(size_t)b * stride4 + i];
+    const int row = (i * 4) / (2 * D), col = i * 4 - row * 2 * D;
+    *(half4*)(dqkv + (size_t)row * 3 * D + D + col) = (half4){(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+}
+
 template <int KVC, bool CAUSAL, int NWB>
-static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, hipStream_t s) {
+static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, hipStream_t s, int Ps, float* kv_part) {
     constexpr int SP = KVC * 32;
     constexpr size_t lds = (size_t)4 * SP * 64 * 2 + (size_t)3 * SP * 4;
     static_assert(lds <= 160 * 1024, "attention backward tile does not fit LDS");
@@ -235,18 +272,25 @@ static int launch_bwd_one(const half_t* qkv, const half_t* o, const half_t* d_ou
         GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel<KVC, CAUSAL, NWB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<KVC, CAUSAL, NWB>), dim3(B * H), dim3(NWB * 64), lds, s, qkv, o, d_out, dqkv, S, H);
+    hipLaunchKernelGGL((attn_bwd_kernel<KVC, CAUSAL, NWB>), dim3(B * H), dim3(NWB * 64), lds, s, qkv, o, d_out, dqkv, S, H, Ps, kv_part);
+    if (Ps > 0) {
+        const int D = H * 64;
+        hipLaunchKernelGGL(attn_shared_kv_reduce_kernel, dim3((Ps * 2 * D / 4 + 255) / 256), dim3(256), 0, s, kv_part, dqkv, B, Ps, D);
+    }
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
 
-int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s) {
+int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s,
+                         int shared_rows, float* kv_part) {
     const int kvc = (S + 31) / 32;
+    GRIP_REQUIRE(shared_rows == 0 || (causal && shared_rows > 0 && shared_rows < S && kv_part && kvc <= 9),
+                 "attention backward: the shared-prefix layout needs a causal mask, 0 < shared rows < S <= 288 and the partial buffer");
     if (kvc > 9) return launch_attention_bwd_tiled(qkv, o, d_out, dqkv, B, S, H, causal, s);    // S > 288: block-tiled kernel (attention_bwd_tiled.hip)
     GRIP_REQUIRE(S >= 1, "attention backward: sequence length %d unsupported", S);
 #define GRIP_ATTN(N)                                                                        \
-    if (kvc <= N) return causal ? launch_bwd_one<N, true, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s)  \
-                                : launch_bwd_one<N, false, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s);
+    if (kvc <= N) return causal ? launch_bwd_one<N, true, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s, shared_rows, kv_part)  \
+                                : launch_bwd_one<N, false, (N >= 4 ? 8 : 4)>(qkv, o, d_out, dqkv, B, S, H, s, 0, nullptr);
     GRIP_ATTN(1) GRIP_ATTN(2) GRIP_ATTN(3) GRIP_ATTN(4) GRIP_ATTN(5) GRIP_ATTN(6) GRIP_ATTN(7) GRIP_ATTN(8) GRIP_ATTN(9)
 #undef GRIP_ATTN
     return GRIP_ERR_ARG;

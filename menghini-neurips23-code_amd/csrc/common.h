@@ -183,15 +183,29 @@ int launch_layernorm_f16(const void* x, const float* gamma, const float* beta, v
 int launch_gather_ln_f16(const void* x, const int32_t* row_index, int row_stride, const float* gamma, const float* beta,
                          void* out, int f32, int n_rows, int d, hipStream_t s);
 int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, void* x, int f32, float* rowstat, int C, int T, int d, int vocab, hipStream_t s);
+                      int prefix_classes, void* x, int f32, float* rowstat, int C, int T, int d, int vocab, hipStream_t s, int shared_rows = 0);
 int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int ld_in, hipStream_t s);
 
 // attention (attention.hip / attention_f32.hip): qkv [B*S, 3*D] -> out [B*S, D]
-int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s);
+// Row addressing shared by the small-S forward and backward kernels.  Plain layout: row r of sequence b is b*S + r.
+// Shared-prefix layout (text tower with ONE learned context for every class, Ps = 1 + n_prefix > 0): the first Ps positions
+// (SOT + context) are the same tokens at the same positions for every class and the mask is causal, so their activations are
+// identical for every class in every layer; the stream holds them ONCE (rows 0 .. Ps-1) followed by the L = S - Ps
+// class-specific positions of each class (row Ps + b*L + (r - Ps)).  Sequence b attends to the shared keys and its own.
+#ifdef __HIPCC__
+__device__ __forceinline__ size_t seq_row(int b, int r, int S, int Ps) {
+    return r < Ps ? (size_t)r : (size_t)Ps + (size_t)b * (S - Ps) + (r - Ps);
+}
+#endif
+
+// shared_rows > 0: shared-prefix row layout (attention.hip, seq_row)
+int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s, int shared_rows = 0);
 int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s);
 int launch_gather_rows(const half_t* x, const int32_t* row_index, int row_stride, half_t* out, int n_rows, int d, hipStream_t s);
 int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s);
-int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
+// shared_rows > 0: shared-prefix layout; kv_part [B, shared_rows, 2, H*64] f32 scratch for the per-sequence dK / dV of the shared keys
+int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s,
+                         int shared_rows = 0, float* kv_part = nullptr);
 int launch_attention_bwd_tiled(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s);
 // backward row kernels (rowops_bwd.hip)
 int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);

@@ -1101,9 +1101,13 @@ int gemm_pick_ksplit(int M, int N, int K) {
     const int nk = K / BK;
     if (force >= 1) return nk % force == 0 ? force : 1;
     if (tiles >= 512) return 1;
-    for (int f : {2, 3, 4, 6, 8})
-        if (nk % f == 0 && nk / f >= 4 && tiles * f >= 256) return f;
-    return 1;
+    int best = 1;
+    for (int f : {2, 3, 4, 6, 8}) {
+        if (nk % f || nk / f < 3) continue;
+        best = f;                                   // a few dozen tiles (the shared-prefix text rows): as many K slices as keep 3 k-steps each
+        if (nk / f >= 4 && tiles * f >= 256) break; // the smallest factor that reaches every CU
+    }
+    return best;
 }
 
 static int launch_ring(int epi, const GemmArgs& a, int nst, dim3 grid, hipStream_t s) {
@@ -1155,7 +1159,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
         double best = 0.85 * fill(tm128 * (a.N / 128), 512);
         variant = 1;
         {
-            const double s4 = 0.70 * fill((int64_t)((a.M + 63) / 64) * (a.N / 128), 768);   // three 48-KiB workgroups per CU
+            double s4 = 0.70 * fill((int64_t)((a.M + 63) / 64) * (a.N / 128), 768);   // three 48-KiB workgroups per CU
+            // fewer 128-row tiles than CUs: the launch is one workgroup per CU whatever the shape, and its time is k-steps x (bytes
+            // a CU stages per step), which the 64-row tile cuts by a quarter (measured at M = 425 and 2 142: 6-25 % faster)
+            if (tm128 * (a.N / 128) <= 256) s4 = 1.0;
             if (s4 > best) { best = s4; variant = 4; }
         }
         if (can_big) {

@@ -136,11 +136,13 @@ int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float
 template <typename RT>
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, int ld_ids, const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, const float* __restrict__ prefix, int P,
-                                                         int prefix_classes, RT* __restrict__ x, float* __restrict__ rowstat, int C, int T, int d, int vocab) {
+                                                         int prefix_classes, RT* __restrict__ x, float* __restrict__ rowstat, int C, int T, int d, int vocab,
+                                                         int Ps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= C * T) return;
-    const int c = row / T, t = row - c * T;
+    // Ps > 0: shared-prefix layout (common.h, seq_row): rows 0 .. Ps-1 are positions 0 .. Ps-1 once (class 0's tokens), then T - Ps rows per class
+    if (row >= Ps + C * (T - Ps)) return;
+    const int c = row < Ps ? 0 : (row - Ps) / (T - Ps), t = row < Ps ? row : Ps + (row - Ps) - c * (T - Ps);
     const int d4 = d >> 2;
     const f32x4* src;
     if (t >= 1 && t <= P) {
@@ -167,12 +169,14 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
 }
 
 int launch_text_embed(const int32_t* token_ids, int ld_ids, const float* tok_emb, const float* pos, const float* prefix, int P,
-                      int prefix_classes, void* x, int f32, float* rowstat, int C, int T, int d, int vocab, hipStream_t s) {
+                      int prefix_classes, void* x, int f32, float* rowstat, int C, int T, int d, int vocab, hipStream_t s, int shared_rows) {
     GRIP_REQUIRE(d % 4 == 0, "text_embed: width %% 4 != 0");
+    GRIP_REQUIRE(shared_rows == 0 || (shared_rows == P + 1 && prefix_classes == 1 && shared_rows < T), "text_embed: shared-prefix layout needs one shared context and shared rows = n_prefix + 1 < T");
+    const int rows = shared_rows + C * (T - shared_rows);
     if (f32)
-        hipLaunchKernelGGL(text_embed_kernel<float>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (float*)x, rowstat, C, T, d, vocab);
+        hipLaunchKernelGGL(text_embed_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (float*)x, rowstat, C, T, d, vocab, shared_rows);
     else
-        hipLaunchKernelGGL(text_embed_kernel<resid_t>, dim3((C * T + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (resid_t*)x, rowstat, C, T, d, vocab);
+        hipLaunchKernelGGL(text_embed_kernel<resid_t>, dim3((rows + 3) / 4), dim3(256), 0, s, token_ids, ld_ids, tok_emb, pos, prefix, P, prefix_classes, (resid_t*)x, rowstat, C, T, d, vocab, shared_rows);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -176,6 +176,10 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     float* dx = nullptr;
     float* dln = nullptr;      // [max(ks_fc, ks_in)][Mp, d] f32 split-K partials of the EPI_F32 input-gradient GEMMs
     int ks_fc = 1, ks_in = 1;  // their split factors (gemm_pick_ksplit)
+    // shared-prefix layout of the text tower (common.h, seq_row): Ps = 1 + P shared leading rows, then S - Ps rows per class
+    int Ps = 0;
+    int rs = 0;                // rows between consecutive sequences for the (sequence, position) -> row gathers: S, or S - Ps
+    float* kv_part = nullptr;  // [batch, Ps, 2, d] f32: per-class shares of the shared keys' dK / dV (train)
     half_t* dxh = nullptr;
     half_t* dh = nullptr;
     half_t* dqkv = nullptr;
@@ -210,7 +214,7 @@ struct grip_tower {
     std::map<void*, TrainState> pending;
 };
 
-static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w, int seq_len = 0) {
+static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w, int seq_len = 0, int shared = 0) {
     const grip_dims& D = t->D;
     GRIP_REQUIRE(batch > 0 && P >= 0 && P <= D.max_prefix, "batch must be positive and 0 <= n_prefix <= max_prefix (batch=%d n_prefix=%d max=%d)", batch, P, D.max_prefix);
     const int64_t d = D.width;
@@ -221,7 +225,10 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     w.S = D.kind == 0 ? D.seq0 + P : (seq_len ? seq_len : D.seq0);
     GRIP_REQUIRE(D.kind == 0 || P < w.S - 1, "text: n_prefix %d does not fit the sequence length %d", P, w.S);
     GRIP_REQUIRE(w.S <= 608, "sequence length %d exceeds the fused-attention limit 608", w.S);
-    w.M = batch * w.S;
+    GRIP_REQUIRE(!shared || (D.kind == 1 && P > 0 && !t->f32), "the shared-prefix layout is the f16 text tower's, with a context (n_prefix > 0)");
+    w.Ps = shared ? P + 1 : 0;
+    w.rs = w.S - w.Ps;
+    w.M = w.Ps + batch * (int64_t)w.rs;
     w.Mp = round_up64(w.M, 256);
     const int64_t Bp = round_up64(batch, 256);
     size_t off = 0;
@@ -270,6 +277,7 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
         w.dcls = (float*)take(Bp * d * 4);
         w.gemb16 = (half_t*)take(Bp * D.embed_dim * 2);
         w.scale = (float*)take(256);
+        if (w.Ps) w.kv_part = (float*)take((size_t)batch * w.Ps * 2 * d * 4);
     }
     w.bytes = off;
     return GRIP_OK;
@@ -327,6 +335,12 @@ extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix
         int rc = carve(t, batch, n_prefix, train, nullptr, w, seq_len);
         if (rc) return rc;
         *bytes = w.bytes;
+        if (t->D.kind == 1 && n_prefix > 0 && !t->f32) {     // either row layout of a text forward fits (GRIP_FWD_SHARED_PREFIX)
+            Workspace ws;
+            rc = carve(t, batch, n_prefix, train, nullptr, ws, seq_len, 1);
+            if (rc) return rc;
+            if (ws.bytes > *bytes) *bytes = ws.bytes;
+        }
         return GRIP_OK;
     } catch (...) { grip_set_error("workspace_bytes: exception"); return GRIP_ERR_ARG; }
 }
@@ -356,7 +370,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
     // 2.2 of the block's 2.9 GFLOP per ViT-B/16 image are never issued, the embedding is unchanged.  GRIP_LAST_BLOCK_FULL=1
     // computes the whole block as the reference does (A/B; the tests hold the two paths equal).
     static const bool last_full = getenv("GRIP_LAST_BLOCK_FULL") && atoi(getenv("GRIP_LAST_BLOCK_FULL")) != 0;
-    const bool rows_only = fold && !last_full;
+    const bool rows_only = fold && !last_full && !w.Ps;
     *compact = false;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
@@ -398,12 +412,12 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             a.f32 = f; a.A = w.xn; a.W = t->wop(lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_BIAS_F16, a, s));
             if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s));
-            else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
+            else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s, w.Ps));
         } else {
             a.A = x; a.W = t->w16 + lw.in_wG; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_bb; a.colsum = F + lw.in_cs; a.rowstat = w.rowstat;
             a.out = qkv; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_LNFOLD_F16, a, s));
-            RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s));
+            RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s, w.Ps));
         }
         a = GemmArgs{};
         a.f32 = f; a.A = att; a.W = t->wop(lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
@@ -431,10 +445,10 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
     return GRIP_OK;
 }
 
-static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t ws_bytes, Workspace& w, int seq_len = 0) {
+static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t ws_bytes, Workspace& w, int seq_len = 0, int shared = 0) {
     GRIP_REQUIRE(t && ws, "null tower / workspace");
     if (!t->finalized) { grip_set_error("tower not finalized: call grip_tower_finalize after filling the weight blobs"); return GRIP_ERR_STATE; }
-    RUN(carve(t, batch, P, train, (char*)ws, w, seq_len));
+    RUN(carve(t, batch, P, train, (char*)ws, w, seq_len, shared));
     if (w.bytes > ws_bytes) { grip_set_error("workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes); return GRIP_ERR_WORKSPACE; }
     GRIP_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
     return GRIP_OK;
@@ -484,23 +498,27 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
 
 extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
                                  int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
-                                 void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream) {
+                                 void* workspace, size_t workspace_bytes, int flags, uint64_t* generation, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 1, "text_forward: not a text tower");
         GRIP_REQUIRE(token_ids && eot_index && out_emb && (n_prefix == 0 || prefix), "text_forward: null pointer");
         GRIP_REQUIRE(n_prefix == 0 || prefix_classes == 1 || prefix_classes == n_class, "text_forward: prefix_classes must be 1 or n_class");
+        GRIP_REQUIRE((flags & ~(GRIP_FWD_TRAIN | GRIP_FWD_SHARED_PREFIX)) == 0, "text_forward: unknown flag bits 0x%x", flags);
+        const int train = flags & GRIP_FWD_TRAIN;
+        // the caller vouches for identical tokens at positions 0 .. n_prefix in every class; exact (f32) towers keep the plain layout
+        const int shared = (flags & GRIP_FWD_SHARED_PREFIX) && n_prefix > 0 && prefix_classes == 1 && !t->f32;
         Workspace w;
-        RUN(check_ws(t, n_class, n_prefix, train, workspace, workspace_bytes, w, seq_len));
+        RUN(check_ws(t, n_class, n_prefix, train, workspace, workspace_bytes, w, seq_len, shared));
         hipStream_t s = (hipStream_t)stream;
         const grip_dims& D = t->D;
         const int d = D.width, f = t->f32;
         const float* F = t->w32;
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, train ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s));
+        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, train ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s, w.Ps));
         resid_t* xf = nullptr;
         bool compact = false;
         RUN(run_blocks(t, w, x0, /*causal=*/1, eot_index, s, &xf, &compact));
-        RUN(launch_gather_ln_f16(xf, compact ? nullptr : eot_index, compact ? 1 : w.S, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, n_class, d, s));
+        RUN(launch_gather_ln_f16(xf, compact ? nullptr : eot_index, compact ? 1 : w.rs, F + t->L.lnpost_g, F + t->L.lnpost_b, w.cls16, f, n_class, d, s));
         GemmArgs a{};
         a.f32 = f; a.A = w.cls16; a.W = t->wop(t->L.projT); a.M = n_class; a.N = D.embed_dim; a.K = d; a.out = out_emb; a.ldc = D.embed_dim;
         RUN(launch_gemm(EPI_F32, a, s));
@@ -579,7 +597,7 @@ static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, hipStrea
         a = GemmArgs{};
         a.A = w.dxh; a.W = W + lw.out_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.out = w.datt; a.ldc = d;
         RUN(launch_gemm(EPI_F16, a, s));
-        RUN(launch_attention_bwd(w.qkv_l[(size_t)l], w.att_l[(size_t)l], w.datt, w.dqkv, w.batch, w.S, H, causal, s));
+        RUN(launch_attention_bwd(w.qkv_l[(size_t)l], w.att_l[(size_t)l], w.datt, w.dqkv, w.batch, w.S, H, causal, s, w.Ps, w.kv_part));
         a = GemmArgs{};
         a.A = w.dqkv; a.W = W + lw.in_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 3 * d; a.out = w.dln; a.ldc = d;
         a.ksplit = w.ks_in; a.split_stride = part;
@@ -599,7 +617,8 @@ static int backward_head_of_tower(grip_tower* t, Workspace& w, const float* grad
     RUN(launch_gemm(EPI_F32, a, s));
     GRIP_CHECK_HIP(hipMemsetAsync(w.dx, 0, (size_t)w.M * d * 4, s));
     GRIP_CHECK_HIP(hipMemsetAsync(w.dxh, 0, (size_t)w.M * d * 2, s));
-    RUN(launch_ln_bwd_scatter(w.x_in[(size_t)D.layers], w.dcls, index, w.S, t->w32 + t->L.lnpost_g, w.dx, w.dxh, w.batch, d, s));
+    // row of (sequence b, position index[b]): b * rs + index[b] in either layout (shared-prefix: Ps + b*(S-Ps) + index - Ps)
+    RUN(launch_ln_bwd_scatter(w.x_in[(size_t)D.layers], w.dcls, index, w.rs, t->w32 + t->L.lnpost_g, w.dx, w.dxh, w.batch, d, s));
     return GRIP_OK;
 }
 
@@ -652,7 +671,10 @@ extern "C" int grip_text_backward_prefix(grip_tower* t, const float* grad_emb, f
         hipStream_t s = (hipStream_t)stream;
         RUN(backward_head_of_tower(t, w, grad_emb, st.eot, s));
         RUN(run_blocks_backward(t, w, 1, s));
-        RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, w.batch, w.S, w.P, st.prefix_classes, t->D.width, s));
+        if (w.Ps)   // shared-prefix layout: every class's share already met in the shared rows (rows 1 .. P)
+            RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, 1, w.S, w.P, 1, t->D.width, s));
+        else
+            RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, w.batch, w.S, w.P, st.prefix_classes, t->D.width, s));
         return GRIP_OK;
     } catch (...) { grip_set_error("text_backward_prefix: exception"); return GRIP_ERR_ARG; }
 }

@@ -4,6 +4,7 @@ torch is used for device memory, streams and autograd bookkeeping only; every FL
 encoders, the head and the losses runs in libgrip_amd.so (csrc/*.hip).
 """
 import ctypes
+import os
 import weakref
 from ctypes import byref, c_int64, c_size_t, c_uint64, c_void_p
 
@@ -224,14 +225,34 @@ class Tower:
         if prefix is not None:
             pc, P = prefix.shape[0], prefix.shape[1]
             prefix = prefix.contiguous().float()
+        flags = native.FWD_TRAIN if train else 0
+        if P and pc == 1 and not self.exact and self.share_text_prefix and self._shares_prefix(token_ids, ids, eot, P):
+            flags |= native.FWD_SHARED_PREFIX
+        self.last_text_flags = flags
         out = torch.empty(C, self.embed_dim, dtype=torch.float32, device=self.device)
         ws = self.workspace(C, P, train, seq_len)
         p, n = self._aligned(ws)
         gen = c_uint64(0)
         native.check(self.lib.grip_text_forward(self.handle, _ptr(ids), _ptr(eot), _ptr(prefix), P, pc, C, seq_len, _ptr(out), p, n,
-                                                int(train), byref(gen), _stream()))
+                                                flags, byref(gen), _stream()))
         ws.generation = gen.value
         return out, ws, (ids, eot, seq_len)
+
+    # One shared context (CoOp / UPT text side): positions 0 .. P hold the same tokens for every class and the mask is causal, so
+    # the engine encodes them once (include/grip_amd.h, GRIP_FWD_SHARED_PREFIX).  GRIP_TEXT_SHARED_PREFIX=0 keeps the plain
+    # n_class x seq_len layout (developer A/B; the tests hold the two equal).
+    share_text_prefix = os.environ.get("GRIP_TEXT_SHARED_PREFIX", "1") != "0"
+
+    @staticmethod
+    def _shares_prefix(token_ids, ids, eot, P):
+        """True when every class has the same tokens at positions 0 .. P and its EOT after them (checked once per token tensor
+        and context length, remembered with the tensor's version counter)."""
+        memo = getattr(token_ids, "_grip_shared", None)
+        if memo is not None and memo[0] == token_ids._version and memo[1] == P:
+            return memo[2]
+        ok = bool(ids.shape[0] >= 2 and ids.shape[1] > P + 1 and (ids[:, :P + 1] == ids[:1, :P + 1]).all().item() and int(eot.min().item()) > P)
+        token_ids._grip_shared = (token_ids._version, P, ok)
+        return ok
 
     def text_backward(self, grad_emb, prefix_shape, ws, generation=0):
         grad_emb = grad_emb.contiguous().float()

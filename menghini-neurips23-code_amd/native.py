@@ -10,7 +10,8 @@ from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrip_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
+FWD_TRAIN, FWD_SHARED_PREFIX = 1, 2      # grip_text_forward flags
 
 
 class GripError(RuntimeError):

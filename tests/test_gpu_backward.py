@@ -202,6 +202,62 @@ def _full_size_text_gradient(m, g, tag, dt, cos_tol=1e-3, rel_tol=3e-2):
             tower.truncate_text_at_eot = True
 
 
+@pytest.mark.parametrize("name,C,P,lens", [("small", 5, 3, (2, 1, 4, 3, 1)), ("ViT-B/16", 102, 16, None), ("ViT-B/16", 2, 4, (1, 6)), ("ViT-B/16", 37, 16, "ragged")])
+def test_shared_prefix_layout_equals_plain(models, name, C, P, lens):
+    """One shared context (CoOp): positions 0 .. P are the same tokens for every class under a causal mask, so the engine encodes
+    them once (GRIP_FWD_SHARED_PREFIX: 1 + P + C * (S - 1 - P) rows instead of C * S).  Same embeddings (train and inference
+    forward) and same prompt gradient as the plain C x S layout, ragged class-name lengths included; class-specific contexts, a
+    single class, or tokens that differ inside the shared positions keep the plain layout."""
+    import grip_amd  # noqa: F401
+    from grip_amd import config, native
+    from grip_amd.engine import TextPrefixFn, text_prefix_forward
+    m = models(name)
+    d = config.get_dims(name)
+    tower = m.text_tower
+    gen = torch.Generator().manual_seed(C * 31 + P)
+    if lens is None:
+        lens = [3] * C
+    elif lens == "ragged":
+        lens = [1 + int(v) for v in torch.randint(0, 9, (C,), generator=gen)]
+    sot, eot = d.vocab_size - 2, d.vocab_size - 1
+    tok = torch.zeros(C, d.context_length, dtype=torch.int32)
+    for c, n in enumerate(lens):
+        row = [sot] + [7] * P + [int(v) for v in torch.randint(10, d.vocab_size - 2, (n,), generator=gen)] + [eot]
+        tok[c, :len(row)] = torch.tensor(row, dtype=torch.int32)
+    prefix0 = _inputs(f"shared.{name}.{C}", (1, P, d.transformer_width), 0.02).cuda()
+    wout = _inputs(f"shared.w.{name}.{C}", (C, d.embed_dim)).cuda()
+    res = {}
+    for share in (True, False):
+        tower.share_text_prefix = share
+        try:
+            t = tok.clone().cuda()
+            pf = prefix0.clone().requires_grad_(True)
+            out = TextPrefixFn.apply(tower, t, pf)
+            assert bool(tower.last_text_flags & native.FWD_SHARED_PREFIX) == share
+            (out * wout).sum().backward()
+            with torch.no_grad():
+                inf = text_prefix_forward(tower, t, pf)
+            res[share] = (out.detach().clone(), inf.clone(), pf.grad.clone())
+        finally:
+            tower.share_text_prefix = True
+    for i, what in enumerate(("train-mode embeddings", "inference embeddings")):
+        a, b = res[True][i], res[False][i]
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
+        assert (1 - cos).max().item() <= 2e-6, f"{what}: 1-cos {(1 - cos).max().item():.2e}"
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * b.abs().max().item())
+    assert_grad_close(res[True][2], res[False][2].cpu().numpy(), "prompt gradient, shared vs plain layout", cos_tol=1e-4, rel_tol=1e-2)
+    # not shareable: per-class contexts, one class, tokens differing inside the shared positions
+    t = tok.clone().cuda()
+    TextPrefixFn.apply(tower, t, prefix0.expand(C, P, -1).contiguous().requires_grad_(True))
+    assert not tower.last_text_flags & native.FWD_SHARED_PREFIX
+    TextPrefixFn.apply(tower, tok[:1].clone().cuda(), prefix0.clone().requires_grad_(True))
+    assert not tower.last_text_flags & native.FWD_SHARED_PREFIX
+    t2 = tok.clone()
+    t2[C - 1, P] = 9
+    TextPrefixFn.apply(tower, t2.cuda(), prefix0.clone().requires_grad_(True))
+    assert not tower.last_text_flags & native.FWD_SHARED_PREFIX
+
+
 def test_golden_vitb16_prompt_gradients(models, golden_vitb16):
     """G3 with gradients: the CoOp step bench.py times -- d = 512, 12 layers, P = 16, EOT-truncated --
     and the VPT prompt gradient through the 12-layer ViT-B/16, against autograd through the reference's own wrappers."""

@@ -34,12 +34,12 @@ def bench(f, reps=40):
 
 
 SHAPES = []
-for tag, M, d in (("text", 2142, 512), ("image", 3408, 768)):
+for tag, M, d in (("text", 2142, 512), ("image", 3408, 768), ("shared", 425, 512)):
     SHAPES += [(f"{tag} qkv fwd", 1, M, 3 * d, d), (f"{tag} out fwd", 3, M, d, d), (f"{tag} fc fwd", 2, M, 4 * d, d), (f"{tag} proj fwd", 3, M, d, 4 * d),
                (f"{tag} proj dgrad", 5, M, 4 * d, d), (f"{tag} fc dgrad", 0, M, d, 4 * d), (f"{tag} out dgrad", 4, M, d, d), (f"{tag} qkv dgrad", 0, M, d, 3 * d)]
 
 print(f"GRIP_GEMM_RING={os.environ.get('GRIP_GEMM_RING', 'auto')} GRIP_GEMM_KSPLIT={os.environ.get('GRIP_GEMM_KSPLIT', 'auto')} variant={variant}")
-total = {"text": 0.0, "image": 0.0}
+total = {"text": 0.0, "image": 0.0, "shared": 0.0}
 for name, epi, M, N, K in SHAPES:
     Mp = (M + 255) // 256 * 256
     A = torch.randn(Mp, K, device="cuda").half()
