@@ -110,16 +110,32 @@ class Loop:
     def pseudolabel_pass(self, model, streams):
         """(i)-(iii) with `model` (the f16 engine, or the exact one for the comparison block)."""
         a = self.args
+        trace = os.environ.get("GRIP_BENCH_TRACE") == "1"     # developer: per-stage wall times of one pass (adds synchronisations)
+        marks = [("start", time.perf_counter())]
+
+        def mark(name):
+            if trace:
+                torch.cuda.synchronize()
+                marks.append((name, time.perf_counter()))
+
         with torch.no_grad():
             txt = model.encode_text(self.zs_tokens)
+            mark("text")
             # every rank encodes its own pool; embeddings are gathered in global (rank-major) order
             local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
             model.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk if model is self.m else a.exact_chunk, streams=streams)
+            mark("encode")
             emb = gdist.allgather_rows(local, self.n_total, a.pool)
             logits, probs, am_l, am_p = engine.cosine_head(emb, txt, model.logit_scale.exp().item())
+            mark("gather+head")
             probs_h = probs.cpu().numpy()
             pred_h = am_p.cpu().numpy()
-        return engine.leaderboard_scan(probs_h, pred_h, self.ranks, self.k)
+            mark("d2h")
+        out = engine.leaderboard_scan(probs_h, pred_h, self.ranks, self.k)
+        mark("scan")
+        if trace and self.rank == 0:
+            print("pass stages (ms): " + ", ".join(f"{n} {(t - marks[i][1]) * 1e3:.2f}" for i, (n, t) in enumerate(marks[1:])), file=sys.stderr)
+        return out
 
     def step(self):
         a = self.args
