@@ -174,6 +174,8 @@ class Tower:
         main = torch.cuda.current_stream()
         for st in self._enc_streams:
             st.wait_stream(main)
+        if hasattr(images, "plan"):
+            images.plan(lo, hi, chunk)      # lazy file pools decode one chunk ahead, never past the shard
         for i, s in enumerate(range(lo, hi, chunk)):
             e = min(s + chunk, hi)
             k = (i & 1) if streams == 2 else 0

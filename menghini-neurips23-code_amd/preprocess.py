@@ -6,6 +6,7 @@ PIL.Image.resize): the coefficient windows are computed here exactly as Pillow's
 `normalize_coeffs_8bpc` do (float64, a = -0.5, 22-bit fixed point)."""
 import functools
 import math
+import os
 from ctypes import c_void_p
 
 import numpy as np
@@ -103,6 +104,12 @@ class ClipPreprocess:
         return out
 
     # ------------------------------------------------------------------ batched path
+    # grip_preprocess_item (include/grip_amd.h), as a numpy record so a chunk's descriptors are filled column-wise
+    _ITEM = np.dtype([("img", "<u8"), ("H", "<i4"), ("W", "<i4"), ("hcoef", "<u8"), ("hbounds", "<u8"), ("hksize", "<i4"), ("W_out", "<i4"),
+                      ("vcoef", "<u8"), ("vbounds", "<u8"), ("vksize", "<i4"), ("H_out", "<i4"), ("crop_left", "<i4"), ("crop_top", "<i4"),
+                      ("tmp", "<u8"), ("out", "<u8")])
+    N_STAGING = 3          # staging buffers in rotation: one being decoded into, one in flight to the device, one spare
+
     @staticmethod
     def _as_u8(img):
         if torch.is_tensor(img):
@@ -114,65 +121,153 @@ class ClipPreprocess:
             raise ValueError(f"expected a uint8 [H, W, 3] image, got {img.shape}")
         return img
 
-    def batch(self, images, out=None):
-        """A list of decoded images (PIL, or uint8 [H, W, 3] arrays, any sizes) -> float32 [B, 3, n_px, n_px] on the device with
-        ONE host-to-device copy and ONE launch pair (grip_preprocess_batch): the images are packed into a single pinned buffer,
-        each gets a descriptor with its own Pillow coefficient tables.  Bit-identical to calling the transform per image."""
-        import ctypes
-        imgs = [self._as_u8(im) for im in images]
-        B, n = len(imgs), self.n_px
+    def _staging(self, min_bytes):
+        """The next page-locked staging buffer of the rotation (grow-only), free to overwrite: the upload that last read it has
+        finished.  Returns (slot index, uint8 numpy view)."""
+        st = self.__dict__.setdefault("_stage", {"k": 0, "bufs": [None] * self.N_STAGING, "events": [None] * self.N_STAGING})
+        k = st["k"] = (st["k"] + 1) % self.N_STAGING
+        if st["events"][k] is not None:
+            st["events"][k].synchronize()
+        if st["bufs"][k] is None or st["bufs"][k].numel() < min_bytes:
+            st["bufs"][k] = torch.empty(max(int(min_bytes), 1 << 20), dtype=torch.uint8).pin_memory()
+        return k, st["bufs"][k].numpy()
+
+    def _upload_and_launch(self, host, packed, extra, out, done_event_slot=None):
+        """`host`: page-locked uint8 tensor holding the chunk's pixels as `packed` (data.decode.Packed) describes; `extra`:
+        {index: uint8 [H,W,3] array} for images outside the buffer.  One host-to-device copy, one descriptor upload, one launch pair."""
+        B, n = len(packed.shapes), self.n_px
         if out is None:
             out = torch.empty(B, 3, n, n, dtype=torch.float32, device=self.device)
         if B == 0:
             return out
         lib = native.lib()
-        sizes = [im.shape[0] * im.shape[1] * 3 for im in imgs]
-        offs = np.concatenate([[0], np.cumsum([(s + 255) // 256 * 256 for s in sizes])]).astype(np.int64)
-        host = torch.empty(int(offs[-1]), dtype=torch.uint8).pin_memory()
-        hv = host.numpy()
-        for im, o, s in zip(imgs, offs, sizes):
-            hv[o:o + s] = im.reshape(-1)
-        dev = host.to(self.device, non_blocking=True)
-        tmp_offs = np.concatenate([[0], np.cumsum([(im.shape[0] * n * 3 + 255) // 256 * 256 for im in imgs])]).astype(np.int64)
+        stream = torch.cuda.current_stream()
+        dev = host[:max(packed.used, 1)].to(self.device, non_blocking=True)
+        if done_event_slot is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._stage["events"][done_event_slot] = ev
+        keep = [dev]
+        H, W = packed.shapes[:, 0].astype(np.int64), packed.shapes[:, 1].astype(np.int64)
+        items = np.zeros(B, dtype=self._ITEM)
+        items["img"] = dev.data_ptr() + packed.offsets
+        for i, arr in extra.items():
+            t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+            keep.append(t)
+            items["img"][i] = t.data_ptr()
+        items["H"], items["W"] = H, W
+        # torchvision Resize(int): shorter side -> n, the other int(n * long / short); crop offsets as CenterCrop rounds them
+        tall = W <= H
+        oh = np.where(tall, (n * H / W).astype(np.int64), n)
+        ow = np.where(tall, n, (n * W / H).astype(np.int64))
+        items["H_out"], items["W_out"] = oh, ow
+        items["crop_top"] = [int(round((int(v) - n) / 2.0)) for v in oh]
+        items["crop_left"] = [int(round((int(v) - n) / 2.0)) for v in ow]
+        for (h, w, o_h, o_w) in {(int(a), int(b), int(c), int(d)) for a, b, c, d in zip(H, W, oh, ow)}:
+            if (o_h, o_w) == (h, w):
+                continue
+            hc, hb, hk = self._table(w, o_w)
+            vc, vb, vk = self._table(h, o_h)
+            sel = (H == h) & (W == w)
+            items["hcoef"][sel], items["hbounds"][sel], items["hksize"][sel] = hc.data_ptr(), hb.data_ptr(), hk
+            items["vcoef"][sel], items["vbounds"][sel], items["vksize"][sel] = vc.data_ptr(), vb.data_ptr(), vk
+        tmp_sizes = (H * n * 3 + 255) // 256 * 256
+        tmp_offs = np.concatenate([[0], np.cumsum(tmp_sizes)])
         tmp = torch.empty(int(tmp_offs[-1]), dtype=torch.uint8, device=self.device)
-        items = (native.PreprocessItem * B)()
-        for i, im in enumerate(imgs):
-            h, w = im.shape[0], im.shape[1]
-            oh, ow = resized_size(h, w, n)
-            it = items[i]
-            it.img, it.H, it.W = dev.data_ptr() + int(offs[i]), h, w
-            it.W_out, it.H_out = ow, oh
-            it.crop_top, it.crop_left = int(round((oh - n) / 2.0)), int(round((ow - n) / 2.0))
-            if (oh, ow) != (h, w):
-                hc, hb, hk = self._table(w, ow)
-                vc, vb, vk = self._table(h, oh)
-                it.hcoef, it.hbounds, it.hksize = hc.data_ptr(), hb.data_ptr(), hk
-                it.vcoef, it.vbounds, it.vksize = vc.data_ptr(), vb.data_ptr(), vk
-            it.tmp = tmp.data_ptr() + int(tmp_offs[i])
-            it.out = out.data_ptr() + i * 3 * n * n * 4
-        desc = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
-        s = c_void_p(torch.cuda.current_stream().cuda_stream)
-        native.check(lib.grip_preprocess_batch(c_void_p(desc.data_ptr()), B, max(im.shape[0] for im in imgs), n,
-                                               c_void_p(self._mean.data_ptr()), c_void_p(self._std.data_ptr()), s))
-        for t in (dev, tmp, desc):
-            t.record_stream(torch.cuda.current_stream())
+        items["tmp"] = tmp.data_ptr() + tmp_offs[:-1]
+        items["out"] = out.data_ptr() + np.arange(B, dtype=np.int64) * (3 * n * n * 4)
+        desc = torch.from_numpy(items.view(np.uint8)).to(self.device)
+        keep += [tmp, desc]
+        native.check(lib.grip_preprocess_batch(c_void_p(desc.data_ptr()), B, int(H.max()), n,
+                                               c_void_p(self._mean.data_ptr()), c_void_p(self._std.data_ptr()), c_void_p(stream.cuda_stream)))
+        for t in keep:
+            t.record_stream(stream)
         return out
 
-    def load_batch(self, paths, workers=8, out=None):
-        """Image files -> preprocessed batch: JPEG / PNG decoding on a thread pool (Pillow's decoders release the GIL), then
-        `batch`.  This replaces the per-item host transform of the reference's datasets (data/dataset.py:56-89)."""
-        from concurrent.futures import ThreadPoolExecutor
+    def batch(self, images, out=None):
+        """A list of decoded images (PIL, or uint8 [H, W, 3] arrays, any sizes) -> float32 [B, 3, n_px, n_px] on the device with
+        ONE host-to-device copy and ONE launch pair (grip_preprocess_batch): the images are packed into a page-locked staging
+        buffer, each gets a descriptor with its own Pillow coefficient tables.  Bit-identical to calling the transform per image."""
+        from .data.decode import Packed, _round
+        imgs = [self._as_u8(im) for im in images]
+        sizes = [im.shape[0] * im.shape[1] * 3 for im in imgs]
+        offs = np.concatenate([[0], np.cumsum([_round(s) for s in sizes])]).astype(np.int64)
+        k, hv = self._staging(int(offs[-1]))
+        for im, o, s in zip(imgs, offs, sizes):
+            hv[o:o + s] = im.reshape(-1)
+        packed = Packed(offs[:-1], np.array([im.shape[:2] for im in imgs], dtype=np.int32).reshape(len(imgs), 2), int(offs[-1]))
+        return self._upload_and_launch(self._stage["bufs"][k], packed, {}, out, done_event_slot=k)
 
-        from PIL import Image
+    def decode_chunk(self, paths, workers=8, processes=0):
+        """Host half of `load_batch`: the files decoded (in parallel) into a staging buffer.  Returns an opaque handle for
+        `finish_chunk`.  Thread-safe against one concurrent `finish_chunk` (the staging buffers rotate), so a caller can decode
+        chunk i+1 on a background thread while chunk i is uploaded and encoded."""
+        from .data import decode as D
+        n = len(paths)
+        if processes > 0:
+            st = self.__dict__.get("_procs")
+            hint = self.__dict__.get("_bytes_per_image", 600 * 1024)
+            if st is None or st["dec"].n_proc != processes:
+                self.close()
+                st = self.__dict__["_procs"] = {"dec": D.ProcessDecoder(processes, max(32 << 20, int(n * hint * 1.5)), slots=self.N_STAGING), "slot": 0,
+                                                "host": [None] * self.N_STAGING, "pinned": [False] * self.N_STAGING, "events": [None] * self.N_STAGING}
+            dec = st["dec"]
+            slot = st["slot"] = (st["slot"] + 1) % self.N_STAGING
+            if st["events"][slot] is not None:
+                st["events"][slot].synchronize()           # the upload that last read this slot has finished: free to overwrite / replace
+            if dec.segs[slot].size < n * hint * 1.1:
+                self._unpin(st, slot)
+                dec.ensure(slot, int(n * hint * 1.5))
+            if st["host"][slot] is None:                   # page-lock the segment once: uploads then run as asynchronous DMA straight out of it
+                st["host"][slot] = torch.from_numpy(dec.slot_view(slot))
+                st["pinned"][slot] = int(torch.cuda.cudart().cudaHostRegister(st["host"][slot].data_ptr(), st["host"][slot].numel(), 0)) == 0
+            packed, overflow = dec.decode(paths, slot)
+            if n:
+                total = packed.used + sum(a.nbytes for a in overflow.values())
+                self.__dict__["_bytes_per_image"] = max(hint if not overflow else 0, total // n + 1)
+            return ("proc", slot, packed, overflow)
+        pool = self.__dict__.get("_pool")
+        if workers > 1 and (pool is None or pool._max_workers != workers):
+            pool = self.__dict__["_pool"] = D.make_thread_pool(workers)
+        hint = self.__dict__.get("_bytes_per_image", 600 * 1024)
+        k, hv = self._staging(int(n * hint * 1.25) + (1 << 20))
+        packed, overflow = D.decode_threads(paths, hv, pool if workers > 1 else None)
+        if n:
+            total = packed.used + sum(a.nbytes for a in overflow.values())
+            self.__dict__["_bytes_per_image"] = max(hint if not overflow else 0, total // n + 1)
+        return ("thr", k, packed, overflow)
 
-        def decode(p):
-            with Image.open(p) as im:
-                return np.asarray(im.convert("RGB"), dtype=np.uint8)
-        if workers > 1 and len(paths) > 1:
-            pool = self.__dict__.get("_pool")
-            if pool is None or pool._max_workers != workers:
-                pool = self.__dict__["_pool"] = ThreadPoolExecutor(max_workers=workers)
-            imgs = list(pool.map(decode, paths))
-        else:
-            imgs = [decode(p) for p in paths]
-        return self.batch(imgs, out=out)
+    def finish_chunk(self, handle, out=None):
+        """Device half of `load_batch`: upload + descriptors + the batched launch pair for a `decode_chunk` handle."""
+        kind, k, packed, overflow = handle
+        if kind == "proc":
+            st = self.__dict__["_procs"]
+            res = self._upload_and_launch(st["host"][k], packed, overflow, out)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            st["events"][k] = ev
+            return res
+        return self._upload_and_launch(self._stage["bufs"][k], packed, overflow, out, done_event_slot=k)
+
+    def load_batch(self, paths, workers=8, out=None, processes=0):
+        """Image files -> preprocessed batch [B, 3, n_px, n_px] on the device: JPEG / PNG decoding in parallel (`workers` threads --
+        Pillow's decoders release the GIL -- or `processes` decode processes around a page-locked shared-memory segment, see
+        data/decode.py), then one upload and one batched launch pair.  This replaces the per-item host transform of the
+        reference's datasets (data/dataset.py:56-89); results are bit-identical to the per-image transform."""
+        return self.finish_chunk(self.decode_chunk(list(paths), workers=workers, processes=processes), out=out)
+
+    @staticmethod
+    def _unpin(st, slot):
+        host = st["host"][slot]
+        if host is not None and st["pinned"][slot]:
+            torch.cuda.cudart().cudaHostUnregister(host.data_ptr())
+        st["host"][slot], st["pinned"][slot] = None, False
+
+    def close(self):
+        """Stop the decode processes and release their shared staging segments (idempotent; also runs at interpreter exit)."""
+        st = self.__dict__.pop("_procs", None)
+        if st is not None:
+            torch.cuda.synchronize()
+            for k in range(self.N_STAGING):
+                self._unpin(st, k)
+            st["dec"].close()

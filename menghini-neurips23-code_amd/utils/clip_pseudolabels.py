@@ -14,21 +14,45 @@ log = logging.getLogger(__name__)
 
 def _pool_images(dataset, transform, device):
     """Images of `dataset.filepaths` in order.  A dataset may carry a pre-decoded tensor pool as
-    `dataset.images` ([N,3,R,R], aligned with filepaths); otherwise files are opened with PIL and
-    decoded on a thread pool and preprocessed in one batched launch per chunk (`transform.load_batch` of the native
-    ClipPreprocess; a foreign transform is applied per image as the reference does)."""
+    `dataset.images` ([N,3,R,R], aligned with filepaths); otherwise the files go through the native input pipeline
+    (`ClipPreprocess.decode_chunk` / `finish_chunk`: parallel decode into a page-locked staging buffer, one upload and one
+    batched launch pair per chunk), with the NEXT chunk decoding on a background thread while the current one is uploaded
+    and encoded.  A foreign transform is applied per image as the reference does (utils/clip_pseudolabels.py:24-29)."""
     images = getattr(dataset, "images", None)
     if images is not None:
         return images
     from PIL import Image
+    paths = list(dataset.filepaths)
+    native_pre = hasattr(transform, "decode_chunk")
+    workers = int(os.environ.get("GRIP_DECODE_WORKERS", str(min(32, os.cpu_count() or 8))))
+    from ..data.decode import default_processes
+    procs = int(os.environ.get("GRIP_DECODE_PROCS", str(default_processes())))
 
     class _Lazy:
-        n = len(dataset.filepaths)
+        n = len(paths)
+
+        def __init__(self):
+            self._ahead = None          # ((lo, hi), future of the decoded chunk)
+            self._stop = self.n
+            self._bg = None
+
+        def plan(self, lo, hi, chunk):
+            """Called by the encoder with the range it is about to walk: the look-ahead never decodes past `hi`."""
+            self._stop = hi
 
         def __call__(self, lo, hi):
-            if hasattr(transform, "load_batch"):      # the native preprocess of clip.load: thread-pool decode + one batched launch
-                return transform.load_batch(dataset.filepaths[lo:hi])
-            return torch.stack([transform(Image.open(p).convert("RGB")) for p in dataset.filepaths[lo:hi]])
+            if not native_pre:
+                return torch.stack([transform(Image.open(p).convert("RGB")) for p in paths[lo:hi]])
+            if self._bg is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._bg = ThreadPoolExecutor(max_workers=1)
+            if self._ahead is not None and self._ahead[0] == (lo, hi):
+                handle = self._ahead[1].result()
+            else:
+                handle = transform.decode_chunk(paths[lo:hi], workers=workers, processes=procs)
+            nlo, nhi = hi, min(hi + (hi - lo), self._stop)
+            self._ahead = ((nlo, nhi), self._bg.submit(transform.decode_chunk, paths[nlo:nhi], workers, procs)) if nlo < nhi else None
+            return transform.finish_chunk(handle)
     return _Lazy()
 
 

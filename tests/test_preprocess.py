@@ -1,6 +1,8 @@
 """CLIP preprocessing: (CPU) the host-side coefficient tables drive a numpy emulation of the two-pass fixed-point resample
 that equals PIL.Image.resize(BICUBIC) bit for bit; (GPU) the HIP kernels give exactly what PIL + the reference's transform
 chain gives (Resize -> CenterCrop -> ToTensor -> Normalize), for down-, up- and no-scaling and odd sizes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -117,6 +119,32 @@ def test_batched_preprocess_equals_per_image_and_pil(n_px, tmp_path):
     for workers in (1, 4):
         assert torch.equal(pre.load_batch(paths, workers=workers), single)
     assert pre.batch([]).shape == (0, 3, n_px, n_px)
+    # decode PROCESSES around the page-locked shared-memory staging segment; a segment too small for the chunk (overflow images are
+    # uploaded one by one) and a staging buffer that has to grow give the same tensor
+    assert torch.equal(pre.load_batch(paths, processes=3), single)
+    assert torch.equal(pre.load_batch(paths[::-1], processes=3), single.flip(0))
+    assert all(pre.__dict__["_procs"]["pinned"][k] for k in range(pre.N_STAGING) if pre.__dict__["_procs"]["host"][k] is not None)
+    pre.close()
+    tight = ClipPreprocess(n_px, "cuda")
+    tight.__dict__["_bytes_per_image"] = 16         # segments far too small at first: overflow uploads, then the slots grow
+    try:
+        for _ in range(4):
+            assert torch.equal(tight.load_batch(paths, processes=2), single)
+    finally:
+        tight.close()
+    small = ClipPreprocess(n_px, "cuda")
+    small.__dict__["_bytes_per_image"] = 16
+    assert torch.equal(small.load_batch(paths, workers=4), single)
+    assert torch.equal(small.load_batch(paths, workers=4), single)
+    # decode_chunk / finish_chunk split: chunk i+1 decoded on another thread while chunk i is uploaded
+    import threading
+    res = {}
+    t = threading.Thread(target=lambda: res.setdefault("h", pre.decode_chunk(paths[3:], workers=2)))
+    h0 = pre.decode_chunk(paths[:3], workers=2)
+    t.start()
+    first = pre.finish_chunk(h0)
+    t.join()
+    assert torch.equal(torch.cat([first, pre.finish_chunk(res["h"])]), single)
 
 
 @pytest.mark.gpu
@@ -151,3 +179,67 @@ def test_pseudolabel_pool_from_image_files_uses_the_batched_loader(tmp_path, mon
     pool = DS(torch.stack([preprocess(Image.open(p)) for p in paths]))
     pseudolabel_top_k(cfg, "Pool", 3, "a photo of a {}", pool, classes, preprocess, m, l2i, "cuda", "small", 1)
     assert (files.filepaths, files.labels) == (pool.filepaths, pool.labels) and len(files.filepaths) > 3
+
+
+def test_decode_backends_pack_the_same_pixels(tmp_path):
+    """data/decode.py (host only): thread and process back ends put every image's RGB pixels into the staging buffer exactly as
+    Image.open(...).convert("RGB") gives them (JPEG, PNG, grey-scale and palette files); what does not fit comes back as overflow."""
+    import grip_amd  # noqa: F401
+    from grip_amd.data import decode as D
+    shm_before = set(os.listdir("/dev/shm"))
+    g = np.random.RandomState(3)
+    paths = []
+    for i in range(13):
+        a = g.randint(0, 256, size=(20 + 3 * i, 50 - 2 * i, 3)).astype(np.uint8)
+        im = Image.fromarray(a)
+        if i % 4 == 1:
+            im = im.convert("L")
+        if i % 4 == 2:
+            im = im.convert("P")
+        p = tmp_path / (f"{i}.jpg" if i % 2 and i % 4 != 2 else f"{i}.png")
+        im.save(p)
+        paths.append(str(p))
+    want = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
+
+    def check(buf, packed, overflow):
+        for i, w in enumerate(want[:len(packed.shapes)]):
+            assert tuple(packed.shapes[i]) == w.shape[:2]
+            got = overflow[i] if i in overflow else buf[packed.offsets[i]:packed.offsets[i] + w.size].reshape(w.shape)
+            assert np.array_equal(got, w), i
+            assert packed.offsets[i] % D.ALIGN == 0
+    buf = np.zeros(1 << 20, dtype=np.uint8)
+    for pool in (None, D.make_thread_pool(4)):
+        packed, overflow = D.decode_threads(paths, buf, pool)
+        assert not overflow and packed.used <= buf.shape[0]
+        check(buf, packed, overflow)
+    tiny = np.zeros(9000, dtype=np.uint8)
+    packed, overflow = D.decode_threads(paths, tiny, D.make_thread_pool(3))
+    assert overflow and len(overflow) < len(paths)
+    check(tiny, packed, overflow)
+    dec = D.ProcessDecoder(3, 1 << 20, slots=2)
+    try:
+        for slot in (0, 1, 0):
+            packed, overflow = dec.decode(paths, slot)
+            assert not overflow
+            check(dec.slot_view(slot), packed, overflow)
+        assert len(dec.decode([], 0)[0].shapes) == 0
+        with pytest.raises(RuntimeError, match="decode worker"):
+            dec.decode(paths[:2] + [str(tmp_path / "missing.png")], 0)
+        packed, overflow = dec.decode(paths[:5], 1)             # the workers survive a failed job
+        check(dec.slot_view(1), packed, overflow)
+        assert not dec.ensure(0, 1000) and dec.ensure(0, 3 << 20)      # slot 0 replaced by a larger segment: workers re-attach
+        packed, overflow = dec.decode(paths, 0)
+        assert not overflow
+        check(dec.slot_view(0), packed, overflow)
+        packed, overflow = dec.decode(paths[:1], 1)             # fewer images than workers
+        check(dec.slot_view(1), packed, overflow)
+    finally:
+        dec.close()
+    dec = D.ProcessDecoder(2, 20000, slots=1)
+    try:
+        packed, overflow = dec.decode(paths, 0)
+        assert overflow
+        check(dec.slot_view(0), packed, overflow)
+    finally:
+        dec.close()
+    assert set(os.listdir("/dev/shm")) <= shm_before          # close() unlinked every segment
