@@ -375,53 +375,7 @@ def secondary_block(loop, lib):
         out["vitl14_336_encode"]["text_L_100_prompts_ms"] = t["ms"]
     del big, xl
     torch.cuda.empty_cache()
-    out["input_pipeline"] = input_pipeline_block(loop)
     return out
-
-
-def input_pipeline_block(loop, n=1536, chunk=512):
-    """SURVEY 8f-2, outside the timed region: image FILES -> embeddings through the lazy file pool of utils.clip_pseudolabels (decode
-    processes into a page-locked shared segment, one upload + one batched resize / crop / normalise launch pair per chunk, the next
-    chunk decoding while the current one is encoded), on ImageNet-sized synthetic JPEGs."""
-    import shutil
-    import tempfile
-    from concurrent.futures import ThreadPoolExecutor
-
-    import numpy as np
-    from PIL import Image
-
-    from grip_amd.data.decode import default_processes
-    from grip_amd.preprocess import ClipPreprocess
-    from grip_amd.utils.clip_pseudolabels import _pool_images
-    d = tempfile.mkdtemp(prefix="grip_jpeg_")
-    try:
-        def make(i):
-            g = np.random.RandomState(i)
-            h, w = int(g.choice([375, 333, 500, 480])), int(g.choice([500, 400, 640]))
-            base = g.randint(0, 256, size=(h // 16 + 1, w // 16 + 1, 3)).astype(np.uint8)
-            p = os.path.join(d, f"{i:05d}.jpg")
-            Image.fromarray(base).resize((w, h), Image.BICUBIC).save(p, quality=90)
-            return p
-        with ThreadPoolExecutor(max_workers=16) as ex:
-            paths = list(ex.map(make, range(n)))
-        pre = ClipPreprocess(loop.d.image_resolution, loop.device)
-        ds = type("Files", (), {"filepaths": paths})()
-        tower = loop.m.visual.tower
-        rates = []
-        for _ in range(3):          # the first walk starts the decode processes and sizes the staging segments
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            with torch.no_grad():
-                pl.encode_pool(tower, _pool_images(ds, pre, loop.device), chunk=chunk)
-            torch.cuda.synchronize()
-            rates.append(n / (time.perf_counter() - t0))
-        pre.close()
-        return {"images_per_sec": max(rates[1:]), "first_walk_images_per_sec": rates[0], "files": n, "chunk": chunk,
-                "decode_processes": int(os.environ.get("GRIP_DECODE_PROCS", str(default_processes()))),
-                "workload": "JPEG files (333-500 x 400-640, quality 90) -> Pillow decode in worker processes -> GPU bicubic resize / crop / "
-                            "normalise (bit-exact with the reference's host transform) -> ViT-B/16 embeddings"}
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
 
 
 def free_port():

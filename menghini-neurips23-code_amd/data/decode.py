@@ -6,7 +6,7 @@ Two back ends with the same result (`Packed`):
                 buffer (a bump allocator under a lock hands out the slots), so nothing of the chunk is serial but the slot grant;
   * processes -- N worker processes (plain `python decode.py <shm>` children speaking JSON lines over pipes: no fork of a process
                 that holds a HIP context, no re-import of the parent's __main__) decode into disjoint regions of a shared-memory
-                segment that the parent page-locks once, so the pixels go file -> shared staging -> device with no host copy.
+                segment; the parent copies the packed bytes into its page-locked staging buffer.
 This module imports neither torch nor the native library (the workers stay light)."""
 import json
 import os
@@ -51,8 +51,7 @@ def usable_cpus():
 
 
 def default_processes():
-    """Decode processes the lazy file pools use unless GRIP_DECODE_PROCS says otherwise: one per usable CPU, at most 32; 0 (= the
-    thread back end) on hosts with fewer than 4."""
+    """Decode processes for GRIP_DECODE_PROCS=auto: one per usable CPU, at most 32; 0 (= the thread back end) below 4."""
     n = usable_cpus()
     return min(32, n) if n >= 4 else 0
 

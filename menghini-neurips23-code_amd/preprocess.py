@@ -204,32 +204,29 @@ class ClipPreprocess:
         chunk i+1 on a background thread while chunk i is uploaded and encoded."""
         from .data import decode as D
         n = len(paths)
+        hint = self.__dict__.get("_bytes_per_image", 600 * 1024)
         if processes > 0:
-            st = self.__dict__.get("_procs")
-            hint = self.__dict__.get("_bytes_per_image", 600 * 1024)
-            if st is None or st["dec"].n_proc != processes:
+            dec = self.__dict__.get("_procs")
+            if dec is None or dec.n_proc != processes:
                 self.close()
-                st = self.__dict__["_procs"] = {"dec": D.ProcessDecoder(processes, max(32 << 20, int(n * hint * 1.5)), slots=self.N_STAGING), "slot": 0,
-                                                "host": [None] * self.N_STAGING, "pinned": [False] * self.N_STAGING, "events": [None] * self.N_STAGING}
-            dec = st["dec"]
-            slot = st["slot"] = (st["slot"] + 1) % self.N_STAGING
-            if st["events"][slot] is not None:
-                st["events"][slot].synchronize()           # the upload that last read this slot has finished: free to overwrite / replace
-            if dec.segs[slot].size < n * hint * 1.1:
-                self._unpin(st, slot)
-                dec.ensure(slot, int(n * hint * 1.5))
-            if st["host"][slot] is None:                   # page-lock the segment once: uploads then run as asynchronous DMA straight out of it
-                st["host"][slot] = torch.from_numpy(dec.slot_view(slot))
-                st["pinned"][slot] = int(torch.cuda.cudart().cudaHostRegister(st["host"][slot].data_ptr(), st["host"][slot].numel(), 0)) == 0
-            packed, overflow = dec.decode(paths, slot)
+                dec = self.__dict__["_procs"] = D.ProcessDecoder(processes, max(32 << 20, int(n * hint * 1.5)), slots=1)
+            if dec.segs[0].size < n * hint * 1.1:
+                dec.ensure(0, int(n * hint * 1.5))
+            packed, overflow = dec.decode(paths, 0)
+            # shared segment -> page-locked staging buffer (a plain copy, split over a few threads; the segment is free again at once).
+            # The segment itself is NOT registered with the HIP runtime for DMA.
+            k, hv = self._staging(packed.used + 1)
+            src, step = dec.slot_view(0), max(1 << 22, (packed.used + 3) // 4)
+            spans = [(o, min(o + step, packed.used)) for o in range(0, packed.used, step)]
+            cp = self.__dict__.get("_copy_pool") or self.__dict__.setdefault("_copy_pool", D.make_thread_pool(4))
+            list(cp.map(lambda se: hv.__setitem__(slice(se[0], se[1]), src[se[0]:se[1]]), spans))
             if n:
                 total = packed.used + sum(a.nbytes for a in overflow.values())
                 self.__dict__["_bytes_per_image"] = max(hint if not overflow else 0, total // n + 1)
-            return ("proc", slot, packed, overflow)
+            return ("thr", k, packed, overflow)
         pool = self.__dict__.get("_pool")
         if workers > 1 and (pool is None or pool._max_workers != workers):
             pool = self.__dict__["_pool"] = D.make_thread_pool(workers)
-        hint = self.__dict__.get("_bytes_per_image", 600 * 1024)
         k, hv = self._staging(int(n * hint * 1.25) + (1 << 20))
         packed, overflow = D.decode_threads(paths, hv, pool if workers > 1 else None)
         if n:
@@ -240,34 +237,17 @@ class ClipPreprocess:
     def finish_chunk(self, handle, out=None):
         """Device half of `load_batch`: upload + descriptors + the batched launch pair for a `decode_chunk` handle."""
         kind, k, packed, overflow = handle
-        if kind == "proc":
-            st = self.__dict__["_procs"]
-            res = self._upload_and_launch(st["host"][k], packed, overflow, out)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            st["events"][k] = ev
-            return res
         return self._upload_and_launch(self._stage["bufs"][k], packed, overflow, out, done_event_slot=k)
 
     def load_batch(self, paths, workers=8, out=None, processes=0):
         """Image files -> preprocessed batch [B, 3, n_px, n_px] on the device: JPEG / PNG decoding in parallel (`workers` threads --
-        Pillow's decoders release the GIL -- or `processes` decode processes around a page-locked shared-memory segment, see
-        data/decode.py), then one upload and one batched launch pair.  This replaces the per-item host transform of the
+        Pillow's decoders release the GIL -- or `processes` decode processes around a shared-memory segment, see
+        data/decode.py), then one upload from a page-locked staging buffer and one batched launch pair.  This replaces the per-item host transform of the
         reference's datasets (data/dataset.py:56-89); results are bit-identical to the per-image transform."""
         return self.finish_chunk(self.decode_chunk(list(paths), workers=workers, processes=processes), out=out)
 
-    @staticmethod
-    def _unpin(st, slot):
-        host = st["host"][slot]
-        if host is not None and st["pinned"][slot]:
-            torch.cuda.cudart().cudaHostUnregister(host.data_ptr())
-        st["host"][slot], st["pinned"][slot] = None, False
-
     def close(self):
-        """Stop the decode processes and release their shared staging segments (idempotent; also runs at interpreter exit)."""
-        st = self.__dict__.pop("_procs", None)
-        if st is not None:
-            torch.cuda.synchronize()
-            for k in range(self.N_STAGING):
-                self._unpin(st, k)
-            st["dec"].close()
+        """Stop the decode processes and release their shared segment (idempotent; also runs at interpreter exit)."""
+        dec = self.__dict__.pop("_procs", None)
+        if dec is not None:
+            dec.close()

@@ -26,7 +26,8 @@ def _pool_images(dataset, transform, device):
     native_pre = hasattr(transform, "decode_chunk")
     workers = int(os.environ.get("GRIP_DECODE_WORKERS", str(min(32, os.cpu_count() or 8))))
     from ..data.decode import default_processes
-    procs = int(os.environ.get("GRIP_DECODE_PROCS", str(default_processes())))
+    procs = os.environ.get("GRIP_DECODE_PROCS", "0")        # decode processes are opt-in (a number, or "auto" = one per usable CPU)
+    procs = default_processes() if procs == "auto" else int(procs)
 
     class _Lazy:
         n = len(paths)

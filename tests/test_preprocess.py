@@ -119,14 +119,13 @@ def test_batched_preprocess_equals_per_image_and_pil(n_px, tmp_path):
     for workers in (1, 4):
         assert torch.equal(pre.load_batch(paths, workers=workers), single)
     assert pre.batch([]).shape == (0, 3, n_px, n_px)
-    # decode PROCESSES around the page-locked shared-memory staging segment; a segment too small for the chunk (overflow images are
-    # uploaded one by one) and a staging buffer that has to grow give the same tensor
+    # decode PROCESSES around a shared-memory segment; a segment too small for the chunk (overflow images are uploaded one by one)
+    # and a staging buffer that has to grow give the same tensor
     assert torch.equal(pre.load_batch(paths, processes=3), single)
     assert torch.equal(pre.load_batch(paths[::-1], processes=3), single.flip(0))
-    assert all(pre.__dict__["_procs"]["pinned"][k] for k in range(pre.N_STAGING) if pre.__dict__["_procs"]["host"][k] is not None)
     pre.close()
     tight = ClipPreprocess(n_px, "cuda")
-    tight.__dict__["_bytes_per_image"] = 16         # segments far too small at first: overflow uploads, then the slots grow
+    tight.__dict__["_bytes_per_image"] = 16         # segment far too small at first: overflow uploads, then it grows
     try:
         for _ in range(4):
             assert torch.equal(tight.load_batch(paths, processes=2), single)
