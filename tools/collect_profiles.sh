@@ -13,9 +13,11 @@ cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats
 fi
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
   N=$(echo $C | cut -d' ' -f1)
+  # (--lookahead 1: the prompt steps encode their own 16 images, so every persistent-GEMM launch in the pass is a full pool chunk and the
+  # per-kernel averages are per-launch figures of the bench's dominant launch, not a mix with the 208-image look-ahead encodes.)
   # (--graph 0: rocprofv3 counter collection aborts on HIP-graph replays -- "incomplete dispatches" -- and then hangs; the encode
   # kernels the counters are wanted for are launched eagerly either way.  timeout: never let a profiler hang eat the box.)
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$N -o r -- python $R/bench.py --no-cpu-baseline --no-secondary --no-exact --graph 0 --pool 13200 --steps 1 --warmup 0 > /dev/null 2>> $OUT/bench_stderr.log
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$N -o r -- python $R/bench.py --no-cpu-baseline --no-secondary --no-exact --graph 0 --lookahead 1 --pool 13200 --steps 1 --warmup 0 > /dev/null 2>> $OUT/bench_stderr.log
   python3 - "$(find /tmp/prof_$N -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$N.csv" <<'PY'
 import csv, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
