@@ -209,6 +209,126 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[RO
         epilogue_rows_impl<EPI, ROWFRAGS, true, PF, PRE>(g, acc, slab, row0, col0, lane, pre);
 }
 
+// ---- 16-byte-store form of the 16-row-pass epilogue (persistent kernel; the three f16-output epilogues of the pool encode).
+// A lane owns EIGHT consecutive columns of one row: 8 lanes cover the wave tile's 64 columns (one 128-byte line), one wave
+// instruction stores 8 rows x 128 B -- half the store (and residual-load) instructions of the 8-byte form above, whose store tail
+// is issue-bound (MI355X_MICROARCH.md: "8 x dwordx4 halves it").  Slab layout: the 16-byte chunk ch (4 floats) of row r sits at
+// position ((ch >> 1) ^ (r & 7)) + 8 * (ch & 1): the even and the odd chunks of a row each fill one 128-byte half, so the fragment
+// writes (8 consecutive lanes = 8 rows, same chunk) and both read-back instructions (8 consecutive lanes = one row's 8 even / odd
+// chunks) touch all 32 banks once.  Row statistics: 3 DPP steps over the row's 8 lanes.
+__device__ __forceinline__ float row8_sum(float v) {
+#define GRIP_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    GRIP_DPP_ADD(0xB1);
+    GRIP_DPP_ADD(0x4E);
+    GRIP_DPP_ADD(0x141);
+#undef GRIP_DPP_ADD
+    return v;
+}
+
+template <int EPI, bool CHECK, bool PRE>
+__device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&acc)[8][4], float* slab, int row0, int col0, int lane, const float2* pre) {
+    constexpr bool FOLD = (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16);
+    constexpr bool RESID = (EPI == EPI_BIAS_RESID_STATS);
+    static_assert(FOLD || RESID, "epilogue_rows8: f16-output epilogues of the pool encode only");
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int col = col0 + c8 * 8;
+    const int ldc = g.ldc;
+    const uint32_t lane_off = (uint32_t)(row0 + r8) * (uint32_t)ldc + (uint32_t)col;
+    auto elem_off = [&](int p, int it) -> uint32_t {
+        if constexpr (CHECK) {
+            int row = row0 + p * 16 + it * 8 + r8;
+            row = row < g.M ? row : g.M - 1;
+            return (uint32_t)row * (uint32_t)ldc + (uint32_t)col;
+        } else {
+            return lane_off + (uint32_t)((p * 16 + it * 8) * ldc);
+        }
+    };
+    half8 res[2][2];
+    auto prefetch = [&](int p, int b) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) res[b][it] = *(const half8*)((const half_t*)g.resid + elem_off(p, it));
+    };
+    f32x4 csum[2], bfold[2];
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            csum[h] = *(const f32x4*)(g.colsum + col + h * 4);
+            bfold[h] = *(const f32x4*)(g.bias + col + h * 4);
+        }
+    }
+    if constexpr (RESID) prefetch(0, 0);
+    // write positions of this lane's four fragment chunks (ch = j * 4 + fgrp), read positions of its two column chunks
+    const int wbase = frow * 64 + (fgrp & 1) * 32;
+    const int wlow = (fgrp >> 1);
+    const int rpos = (c8 ^ r8) * 4;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(slab + wbase + (((j * 2 + wlow) ^ (frow & 7)) * 4)) = acc[p][j];
+        if constexpr (RESID)
+            if (p + 1 < 8) prefetch(p + 1, (p + 1) & 1);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rl = it * 8 + r8;
+            f32x4 v[2];
+            v[0] = *(const f32x4*)(slab + rl * 64 + rpos);
+            v[1] = *(const f32x4*)(slab + rl * 64 + 32 + rpos);
+            const int row = row0 + p * 16 + rl;
+            const uint32_t o = elem_off(p, it);
+            if constexpr (RESID) {
+                const half8 rh = res[p & 1][it];
+                v[0] += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                v[1] += (f32x4){(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
+                const float sm = row8_sum(((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3])));
+                float sq = __builtin_fmaf(v[0][0], v[0][0], __builtin_fmaf(v[0][1], v[0][1], __builtin_fmaf(v[0][2], v[0][2], v[0][3] * v[0][3])));
+                sq = __builtin_fmaf(v[1][0], v[1][0], __builtin_fmaf(v[1][1], v[1][1], __builtin_fmaf(v[1][2], v[1][2], __builtin_fmaf(v[1][3], v[1][3], sq))));
+                sq = row8_sum(sq);
+                if (c8 == 0 && (!CHECK || row < g.M))
+                    ((float2*)g.stat_part)[(uint32_t)row * (uint32_t)(g.N >> 6) + (uint32_t)(col0 >> 6)] = make_float2(sm, sq);
+            }
+            float2 st = make_float2(0.f, 0.f);
+            if constexpr (FOLD) {
+                if constexpr (PRE) {
+                    const int src = (((p & 3) * 16 + rl) << 2);
+                    const float2 pv = pre[p >> 2];
+                    st.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.x)));
+                    st.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.y)));
+                } else {
+                    int rr_ = row;
+                    if constexpr (CHECK) rr_ = rr_ < g.M ? rr_ : g.M - 1;
+                    st = ((const float2*)g.rowstat)[rr_];
+                }
+            }
+            if (!CHECK || row < g.M) {
+                if constexpr (FOLD) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) v[h] = (v[h] - csum[h] * st.x) * st.y + bfold[h];
+                    if constexpr (EPI == EPI_LNFOLD_GELU_F16) {
+                        if (g.out2)
+                            *(half8*)((half_t*)g.out2 + o) = (half8){(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
+                                                                    (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) v[h] = (f32x4){quick_gelu(v[h][0]), quick_gelu(v[h][1]), quick_gelu(v[h][2]), quick_gelu(v[h][3])};
+                    }
+                }
+                *(half8*)((half_t*)g.out + o) = (half8){(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
+                                                       (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI, bool PRE>
+__device__ __forceinline__ void epilogue_rows8(const GemmArgs& g, f32x4 (&acc)[8][4], float* slab, int row0, int col0, int lane, const float2* pre) {
+    if (row0 + 128 <= g.M)
+        epilogue_rows8_impl<EPI, false, PRE>(g, acc, slab, row0, col0, lane, pre);
+    else
+        epilogue_rows8_impl<EPI, true, PRE>(g, acc, slab, row0, col0, lane, pre);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -725,7 +845,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
 // boundaries of tile t and land while tile t's epilogue runs, so a tile no longer starts with an exposed HBM/L2 round trip
 // (~2 us of a ~32 us K = 768 tile) nor ends with an idle DMA queue.  The epilogue slabs therefore cannot reuse the stage
 // buffers: they are 16-row, 4 KiB, swizzled slabs in the 32 KiB of LDS beside the two 64 KiB stages.
-template <int EPI>
+template <int EPI, bool W8 = false>
 __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m, int tiles_n, int colgroup) {
     constexpr int BMT = 256, BNT = 256, NW = 8, WN = 4;
     constexpr int STAGE = (BMT + BNT) * BK;       // halfs per stage (BK = 64)
@@ -882,7 +1002,10 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
             mfma_set(1);
             spread();
         }
-        epilogue_rows<EPI, 8, 1, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
+        if constexpr (W8)
+            epilogue_rows8<EPI, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
+        else
+            epilogue_rows<EPI, 8, 1, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
         if (!has_next) break;
         par = (par + nk) & 1;
         t = t_next;
@@ -1070,6 +1193,27 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
         }                                                                                                                   \
         hipLaunchKernelGGL((gemm_k64p_kernel<E>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                                \
     } break;
+#define GRIP_GEMM_CASE8(E)                                                                                                  \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64p_kernel<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_k64p_kernel<E, true>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                          \
+    } break;
+    // GRIP_GEMM_EPI8=0: the 8-byte-store epilogue for the three pool-encode epilogues too (developer A/B)
+    static const bool epi8 = !(getenv("GRIP_GEMM_EPI8") && atoi(getenv("GRIP_GEMM_EPI8")) == 0);
+    if (epi8 && (epi == EPI_LNFOLD_F16 || epi == EPI_LNFOLD_GELU_F16 || epi == EPI_BIAS_RESID_STATS)) {
+        switch (epi) {
+            GRIP_GEMM_CASE8(EPI_LNFOLD_F16)
+            GRIP_GEMM_CASE8(EPI_LNFOLD_GELU_F16)
+            GRIP_GEMM_CASE8(EPI_BIAS_RESID_STATS)
+        }
+        GRIP_CHECK_HIP(hipGetLastError());
+        return GRIP_OK;
+    }
+#undef GRIP_GEMM_CASE8
     switch (epi) {
         GRIP_GEMM_CASE(EPI_F32)
         GRIP_GEMM_CASE(EPI_BIAS_F16)
