@@ -329,6 +329,72 @@ __device__ __forceinline__ void epilogue_rows8(const GemmArgs& g, f32x4 (&acc)[8
         epilogue_rows8_impl<EPI, true, PRE>(g, acc, slab, row0, col0, lane, pre);
 }
 
+// ---- Direct form (no LDS transposition at all; persistent kernel, EMODE 2; LayerNorm-folded epilogues).  The kernel reads its
+// W fragments with the rows of the wave's 64-column tile PERMUTED -- MFMA row m of column block j is tile column
+// (m >> 2) * 16 + j * 4 + (m & 3) -- so a lane's acc[i][0..3] are SIXTEEN consecutive columns (lane >> 4) * 16 .. + 15 of row
+// i * 16 + (lane & 15): the lane stores 32 contiguous bytes (two 16-byte stores back to back), the four lanes l, l + 16, l + 32,
+// l + 48 complete the row's 128-byte line, and no slab write / wave barrier / slab read stands between the accumulators and the
+// store.  Measured against the 16-byte slab form (r02, TF/s in the loop): c_fc (QuickGELU: the epilogue is VALU-heavy and the slab
+// traffic competes with it) 869-878 -> 903; QKV 947-958 -> 858 and the residual epilogue 1 008-1 022 -> 954-962 (store-bound
+// epilogues: whole-line stores win); with the lane's 32 bytes split into two column passes (half the coefficient registers) c_fc
+// falls to 852-856.  So this form serves c_fc only.
+template <int EPI, bool CHECK, bool PRE>
+__device__ __forceinline__ void epilogue_direct_impl(const GemmArgs& g, f32x4 (&acc)[8][4], int row0, int col0, int lane, const float2* pre) {
+    static_assert(EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16, "epilogue_direct: LayerNorm-folded epilogues only");
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int col = col0 + fgrp * 16;
+    const int ldc = g.ldc;
+    const uint32_t lane_off = (uint32_t)(row0 + frow) * (uint32_t)ldc + (uint32_t)col;
+    auto pack8 = [](const f32x4& a, const f32x4& b) {
+        return (half8){(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+    };
+    f32x4 csum[4], bfold[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        csum[j] = *(const f32x4*)(g.colsum + col + j * 4);
+        bfold[j] = *(const f32x4*)(g.bias + col + j * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + i * 16 + frow;
+        const uint32_t o = CHECK ? (uint32_t)(row < g.M ? row : g.M - 1) * (uint32_t)ldc + (uint32_t)col : lane_off + (uint32_t)(i * 16 * ldc);
+        float2 st;
+        if constexpr (PRE) {
+            const int src = (((i & 3) * 16 + frow) << 2);
+            const float2 pv = pre[i >> 2];
+            st.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.x)));
+            st.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.y)));
+        } else {
+            int rr_ = row;
+            if constexpr (CHECK) rr_ = rr_ < g.M ? rr_ : g.M - 1;
+            st = ((const float2*)g.rowstat)[rr_];
+        }
+        if (!CHECK || row < g.M) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (acc[i][j] - csum[j] * st.x) * st.y + bfold[j];
+            if constexpr (EPI == EPI_LNFOLD_GELU_F16) {
+                if (g.out2) {
+                    *(half8*)((half_t*)g.out2 + o) = pack8(v[0], v[1]);
+                    *(half8*)((half_t*)g.out2 + o + 8) = pack8(v[2], v[3]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (f32x4){quick_gelu(v[j][0]), quick_gelu(v[j][1]), quick_gelu(v[j][2]), quick_gelu(v[j][3])};
+            }
+            *(half8*)((half_t*)g.out + o) = pack8(v[0], v[1]);
+            *(half8*)((half_t*)g.out + o + 8) = pack8(v[2], v[3]);
+        }
+    }
+}
+
+template <int EPI, bool PRE>
+__device__ __forceinline__ void epilogue_direct(const GemmArgs& g, f32x4 (&acc)[8][4], int row0, int col0, int lane, const float2* pre) {
+    if (row0 + 128 <= g.M)
+        epilogue_direct_impl<EPI, false, PRE>(g, acc, row0, col0, lane, pre);
+    else
+        epilogue_direct_impl<EPI, true, PRE>(g, acc, row0, col0, lane, pre);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -845,7 +911,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
 // boundaries of tile t and land while tile t's epilogue runs, so a tile no longer starts with an exposed HBM/L2 round trip
 // (~2 us of a ~32 us K = 768 tile) nor ends with an idle DMA queue.  The epilogue slabs therefore cannot reuse the stage
 // buffers: they are 16-row, 4 KiB, swizzled slabs in the 32 KiB of LDS beside the two 64 KiB stages.
-template <int EPI, bool W8 = false>
+// EMODE: 0 = 8-byte-store slab epilogue (every epilogue), 1 = 16-byte-store slab epilogue, 2 = direct epilogue with permuted W
+// fragment rows (1 and 2: the three f16-output epilogues of the pool encode).
+template <int EPI, int EMODE = 0>
 __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m, int tiles_n, int colgroup) {
     constexpr int BMT = 256, BNT = 256, NW = 8, WN = 4;
     constexpr int STAGE = (BMT + BNT) * BK;       // halfs per stage (BK = 64)
@@ -901,29 +969,45 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     };
 
     const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
     const int r0 = wave * GI * 8;
+    // Source-side swizzle: LDS slot (row, c) receives source chunk c ^ key(row).  key = row & 7 for the A rows (and for W in
+    // EMODE 0 / 1).  EMODE 2 reads the W fragments through the row permutation of epilogue_direct, under which the eight rows a
+    // fragment read touches per LDS cycle are {a * 16 + j * 4 + b: a in 0..1, b in 0..3}: key = (row & 3) | ((row >> 4) & 1) << 2
+    // keeps those reads conflict-free.  A wave's 64 staged rows are rows i * 8 + srow of a 64-row block, so bit 4 is (i >> 1) & 1.
+    int schunk[2];
+    if (EMODE == 2 && r0 >= BMT) {
+        schunk[0] = ((lane & 7) ^ (srow & 3)) * 8;
+        schunk[1] = schunk[0] ^ 32;
+    } else {
+        schunk[0] = schunk[1] = ((lane & 7) ^ srow) * 8;
+    }
     auto tile_src = [&](int tile) {
         int tm, tn;
         tile_coords(tile, tm, tn);
-        return (r0 < BMT ? (const half_t*)g.A + (size_t)(tm * BMT + r0 + srow) * K : (const half_t*)g.W + (size_t)(tn * BNT + r0 - BMT + srow) * K) + schunk * 8;
+        return r0 < BMT ? (const half_t*)g.A + (size_t)(tm * BMT + r0 + srow) * K : (const half_t*)g.W + (size_t)(tn * BNT + r0 - BMT + srow) * K;
     };
     auto stage = [&](int buf, const half_t* src, int kt) {
         half_t* dst = lds2 + buf * STAGE + r0 * BK;
         const half_t* sp = src + (size_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < GI; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)i * 8 * K), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)i * 8 * K + schunk[(i >> 1) & 1]), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
+    constexpr int BJ = (EMODE == 2 ? 4 : 16);     // LDS rows between a wave's consecutive W fragments
     int a_off[2], b_off[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
         a_off[kk] = (wr * 128 + frow) * BK + chunk * 8;
-        b_off[kk] = BMT * BK + (wc * 64 + frow) * BK + chunk * 8;
+        if constexpr (EMODE == 2) {
+            const int key = (frow & 3) | (((frow >> 2) & 1) << 2);
+            b_off[kk] = BMT * BK + (wc * 64 + (frow >> 2) * 16 + (frow & 3)) * BK + (((kk * 4 + fgrp) ^ key) * 8);
+        } else {
+            b_off[kk] = BMT * BK + (wc * 64 + frow) * BK + chunk * 8;
+        }
     }
 
     f32x4 acc[8][4];
@@ -931,7 +1015,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     auto load_frags = [&](int set, int buf, int kk) {
         const half_t* st = lds2 + buf * STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[set][j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
+        for (int j = 0; j < 4; ++j) fb[set][j] = *(const half8*)(st + b_off[kk] + j * BJ * BK);
 #pragma unroll
         for (int i = 0; i < 8; ++i) fa[set][i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
     };
@@ -967,7 +1051,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
         if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_STATS) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 b = *(const f32x4*)(g.bias + n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
+                const f32x4 b = *(const f32x4*)(g.bias + n0 + wc * 64 + (EMODE == 2 ? (lane >> 4) * 16 + j * 4 : j * 16 + (lane >> 4) * 4));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i][j] = b;
             }
@@ -1002,7 +1086,9 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
             mfma_set(1);
             spread();
         }
-        if constexpr (W8)
+        if constexpr (EMODE == 2)
+            epilogue_direct<EPI, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, pre);
+        else if constexpr (EMODE == 1)
             epilogue_rows8<EPI, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
         else
             epilogue_rows<EPI, 8, 1, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
@@ -1193,27 +1279,38 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
         }                                                                                                                   \
         hipLaunchKernelGGL((gemm_k64p_kernel<E>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                                \
     } break;
-#define GRIP_GEMM_CASE8(E)                                                                                                  \
+#define GRIP_GEMM_CASE_M(E, MODE)                                                                                           \
     case E: {                                                                                                               \
         static bool configured = false;                                                                                     \
         if (!configured) {                                                                                                  \
-            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64p_kernel<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64p_kernel<E, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             configured = true;                                                                                              \
         }                                                                                                                   \
-        hipLaunchKernelGGL((gemm_k64p_kernel<E, true>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                          \
+        hipLaunchKernelGGL((gemm_k64p_kernel<E, MODE>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                          \
     } break;
-    // GRIP_GEMM_EPI8=0: the 8-byte-store epilogue for the three pool-encode epilogues too (developer A/B)
-    static const bool epi8 = !(getenv("GRIP_GEMM_EPI8") && atoi(getenv("GRIP_GEMM_EPI8")) == 0);
-    if (epi8 && (epi == EPI_LNFOLD_F16 || epi == EPI_LNFOLD_GELU_F16 || epi == EPI_BIAS_RESID_STATS)) {
-        switch (epi) {
-            GRIP_GEMM_CASE8(EPI_LNFOLD_F16)
-            GRIP_GEMM_CASE8(EPI_LNFOLD_GELU_F16)
-            GRIP_GEMM_CASE8(EPI_BIAS_RESID_STATS)
+    // Epilogue form of the three pool-encode epilogues: 0 = 8-byte stores through the slab, 1 = 16-byte stores through the slab,
+    // 2 = direct with permuted W fragment rows (LayerNorm-folded epilogues).  Default 1 for QKV and the residual GEMMs, 2 for c_fc
+    // (see epilogue_direct).  GRIP_GEMM_EMODE=<m> forces one mode, three digits one each for QKV / c_fc / residual (developer A/B).
+    static const int emode_env = getenv("GRIP_GEMM_EMODE") ? atoi(getenv("GRIP_GEMM_EMODE")) : 121;
+    int emode = emode_env < 100 ? emode_env : (epi == EPI_LNFOLD_F16 ? emode_env / 100 : epi == EPI_LNFOLD_GELU_F16 ? (emode_env / 10) % 10 : emode_env % 10);
+    if (epi == EPI_BIAS_RESID_STATS && emode == 2) emode = 1;
+    if (emode != 0 && (epi == EPI_LNFOLD_F16 || epi == EPI_LNFOLD_GELU_F16 || epi == EPI_BIAS_RESID_STATS)) {
+        if (emode == 2) {
+            switch (epi) {
+                GRIP_GEMM_CASE_M(EPI_LNFOLD_F16, 2)
+                GRIP_GEMM_CASE_M(EPI_LNFOLD_GELU_F16, 2)
+            }
+        } else {
+            switch (epi) {
+                GRIP_GEMM_CASE_M(EPI_LNFOLD_F16, 1)
+                GRIP_GEMM_CASE_M(EPI_LNFOLD_GELU_F16, 1)
+                GRIP_GEMM_CASE_M(EPI_BIAS_RESID_STATS, 1)
+            }
         }
         GRIP_CHECK_HIP(hipGetLastError());
         return GRIP_OK;
     }
-#undef GRIP_GEMM_CASE8
+#undef GRIP_GEMM_CASE_M
     switch (epi) {
         GRIP_GEMM_CASE(EPI_F32)
         GRIP_GEMM_CASE(EPI_BIAS_F16)
