@@ -9,15 +9,20 @@
 //   P = exp(s - max)       f32, packed to f16 in place: two score tiles form one 32-wide K chunk of
 //                          the second MFMA without any cross-lane movement.
 //   O^T = V^T P^T          A = V^T fragments, one ds_read_b128 each from a blocked LDS image of V (vt_index, common.h),
-//                          B = the packed P registers.
-//                          Each lane ends with 4 consecutive head-dim values of its own query row,
-//                          divides by its own row sum and stores 8 bytes.
+//                          B = the packed P registers.  The image holds the head dims PERMUTED (vt_index_fwd): MFMA row m of
+//                          block nf is dim (m >> 2) * 16 + nf * 4 + (m & 3), so a lane ends with the SIXTEEN consecutive
+//                          head-dim values (lane >> 4) * 16 .. + 15 of its own query row, divides by its own row sum and
+//                          stores them as two 16-byte pieces (the store tail is issue-bound: four 8-byte stores per lane
+//                          and tile before, 433 -> see DESIGN.md).
 // K is stored [kv][64] with the 16-byte chunk index XOR (kv & 7): conflict-free ds_read_b128.
 // Padding keys (kv >= S) are zero-filled and masked to -inf; causal masking for the text tower.
 #include <math.h>
 #include <stdlib.h>
 
 #include "common.h"
+
+// Forward V image: dim d sits where vt_index would put dim ((d >> 2) & 3) * 16 + (d >> 4) * 4 + (d & 3).
+__device__ __forceinline__ int vt_index_fwd(int key, int d) { return vt_index(key, ((d >> 2) & 3) * 16 + (d >> 4) * 4 + (d & 3)); }
 
 // IEEE-754-2019 maximum: compiles to v_maximum3_f32 (two ops per four scores); fmaxf chains cost a v_max per pair plus a
 // canonicalising v_max per MFMA result.
@@ -82,11 +87,11 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
     }
     if (qrow < S && do_store) {
         const float inv = __builtin_amdgcn_rcpf(osum[0]);
-        half_t* op = orow + lg * 4;
+        half_t* op = orow + lg * 16;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const f32x4 v = o[nf] * inv;
-            *(half4*)(op + nf * 16) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 a = o[2 * h] * inv, b = o[2 * h + 1] * inv;
+            *(half8*)(op + h * 8) = (half8){(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
         }
     }
 }
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_fwd_kernel(const half_t* __r
         if (r0 < S) v0 = *(const half8*)(base + seq_row(b, r0, S, Ps) * ld + 2 * D + chunk * 8);
         if (r0 + 1 < S) v1 = *(const half8*)(base + seq_row(b, r0 + 1, S, Ps) * ld + 2 * D + chunk * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *(half2v*)(Vt + vt_index(r0, chunk * 8 + j)) = (half2v){v0[j], v1[j]};
+        for (int j = 0; j < 8; ++j) *(half2v*)(Vt + vt_index_fwd(r0, chunk * 8 + j)) = (half2v){v0[j], v1[j]};
     }
     __syncthreads();
 
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(const half_t* __
             const int r0 = 2 * (rblk * 32 + lane_rp);
             if (r0 < SP) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *(half2v*)(Vt + vt_index(r0, chunk * 8 + j)) = (half2v){v0[n][j], v1[n][j]};
+                for (int j = 0; j < 8; ++j) *(half2v*)(Vt + vt_index_fwd(r0, chunk * 8 + j)) = (half2v){v0[n][j], v1[n][j]};
             }
         }
     };
