@@ -217,7 +217,11 @@ def pmc_entry(kernel):
     (bytes_per_launch, mfma_util) or (None, None)."""
     try:
         with open(os.path.join(REPO, TRAFFIC_FILE)) as f:
-            t = json.load(f)["kernels"][kernel.split(" [")[0]]
+            kernels = json.load(f)["kernels"]
+        name = kernel.split(" [")[0]
+        if name not in kernels:         # the persistent GEMM carries its epilogue form as a second template argument: <9> -> <9, 1>
+            name = next(k for k in kernels if k.startswith(name[:-1] + ","))
+        t = kernels[name]
         return t.get("bytes_per_launch"), t.get("mfma_util")
     except Exception:
         return None, None
