@@ -329,6 +329,76 @@ __device__ __forceinline__ void epilogue_rows8(const GemmArgs& g, f32x4 (&acc)[8
         epilogue_rows8_impl<EPI, true, PRE>(g, acc, slab, row0, col0, lane, pre);
 }
 
+// ---- f16-slab form (persistent kernel, EMODE 4; LayerNorm-folded epilogues).  The fold arithmetic (and QuickGELU) needs only the
+// row's (mean, rstd) and the column's coefficients, both of which a lane knows in the FRAGMENT layout -- so it is applied to the
+// accumulators in place and the values are rounded to f16 BEFORE the transposition: a 16-row pass is 2 KiB instead of 4, the
+// wave's slab holds TWO passes, and pass p + 1 is computed and written while pass p's read-back and stores are in flight (the
+// f32 forms serialise write -> read -> store per pass on one LDS round trip each).  Slab row = 128 B; the 16-byte chunk index is
+// XORed with (row & 7) and the two 8-byte halves of a chunk are swapped for rows >= 8, which keeps the 8-byte fragment writes
+// (16 lanes = 16 rows per cycle) and the 16-byte read-backs conflict-free.  Stores as in EMODE 1: 8 rows x 128 B per instruction.
+template <int EPI, bool CHECK, bool PRE>
+__device__ __forceinline__ void epilogue_rows8h_impl(const GemmArgs& g, f32x4 (&acc)[8][4], half_t* slab, int row0, int col0, int lane, const float2* pre) {
+    static_assert(EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16, "epilogue_rows8h: LayerNorm-folded epilogues only");
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int ldc = g.ldc;
+    f32x4 csum[4], bfold[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        csum[j] = *(const f32x4*)(g.colsum + col0 + j * 16 + fgrp * 4);
+        bfold[j] = *(const f32x4*)(g.bias + col0 + j * 16 + fgrp * 4);
+    }
+    const uint32_t lane_off = (uint32_t)(row0 + r8) * (uint32_t)ldc + (uint32_t)(col0 + c8 * 8);
+    // write offsets (halfs) of this lane's four 8-byte pieces inside a pass buffer, read offset of its 16-byte chunk
+    const int whalf = ((fgrp & 1) ^ (frow >> 3)) * 4;
+    const int wrow = frow * 64;
+    const int wx = frow & 7;
+    const int roff = r8 * 64 + ((c8 ^ r8) * 8);          // rows r8 and r8 + 8 share (row & 7)
+    auto produce = [&](int p) {
+        float2 st;
+        if constexpr (PRE) {
+            const int src = (((p & 3) * 16 + frow) << 2);
+            const float2 pv = pre[p >> 2];
+            st.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.x)));
+            st.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.y)));
+        } else {
+            int rr_ = row0 + p * 16 + frow;
+            rr_ = rr_ < g.M ? rr_ : g.M - 1;
+            st = ((const float2*)g.rowstat)[rr_];
+        }
+        half_t* buf = slab + (p & 1) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = (acc[p][j] - csum[j] * st.x) * st.y + bfold[j];
+            if constexpr (EPI == EPI_LNFOLD_GELU_F16) v = (f32x4){quick_gelu(v[0]), quick_gelu(v[1]), quick_gelu(v[2]), quick_gelu(v[3])};
+            *(half4*)(buf + wrow + (((j * 2 + (fgrp >> 1)) ^ wx) * 8) + whalf) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+    };
+    produce(0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p + 1 < 8) produce(p + 1);
+        __builtin_amdgcn_wave_barrier();
+        const half_t* buf = slab + (p & 1) * 1024;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            half8 v = *(const half8*)(buf + it * 512 + roff);
+            if (it == 1) v = (half8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};      // rows >= 8 keep their halves swapped
+            const int row = row0 + p * 16 + it * 8 + r8;
+            if (!CHECK || row < g.M) *(half8*)((half_t*)g.out + (CHECK ? (uint32_t)row * (uint32_t)ldc + (uint32_t)(col0 + c8 * 8) : lane_off + (uint32_t)((p * 16 + it * 8) * ldc))) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI, bool PRE>
+__device__ __forceinline__ void epilogue_rows8h(const GemmArgs& g, f32x4 (&acc)[8][4], half_t* slab, int row0, int col0, int lane, const float2* pre) {
+    if (row0 + 128 <= g.M)
+        epilogue_rows8h_impl<EPI, false, PRE>(g, acc, slab, row0, col0, lane, pre);
+    else
+        epilogue_rows8h_impl<EPI, true, PRE>(g, acc, slab, row0, col0, lane, pre);
+}
+
 // ---- Direct form (no LDS transposition at all; persistent kernel, EMODE 2; LayerNorm-folded epilogues).  The kernel reads its
 // W fragments with the rows of the wave's 64-column tile PERMUTED -- MFMA row m of column block j is tile column
 // (m >> 2) * 16 + j * 4 + (m & 3) -- so a lane's acc[i][0..3] are SIXTEEN consecutive columns (lane >> 4) * 16 .. + 15 of row
@@ -1086,7 +1156,9 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
             mfma_set(1);
             spread();
         }
-        if constexpr (EMODE == 2)
+        if constexpr (EMODE == 4)
+            epilogue_rows8h<EPI, true>(g, acc, (half_t*)slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
+        else if constexpr (EMODE == 2)
             epilogue_direct<EPI, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, m0 + wr * 128, n0 + wc * 64, lane, pre);
         else if constexpr (EMODE == 1)
             epilogue_rows8<EPI, (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16)>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
@@ -1288,14 +1360,22 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
         }                                                                                                                   \
         hipLaunchKernelGGL((gemm_k64p_kernel<E, MODE>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                          \
     } break;
-    // Epilogue form of the three pool-encode epilogues: 0 = 8-byte stores through the slab, 1 = 16-byte stores through the slab,
-    // 2 = direct with permuted W fragment rows (LayerNorm-folded epilogues).  Default 1 for QKV and the residual GEMMs, 2 for c_fc
-    // (see epilogue_direct).  GRIP_GEMM_EMODE=<m> forces one mode, three digits one each for QKV / c_fc / residual (developer A/B).
-    static const int emode_env = getenv("GRIP_GEMM_EMODE") ? atoi(getenv("GRIP_GEMM_EMODE")) : 121;
+    // Epilogue form of the three pool-encode epilogues: 0 = 8-byte stores through the f32 slab, 1 = 16-byte stores through the f32
+    // slab, 2 = direct with permuted W fragment rows, 4 = fold arithmetic in the fragment layout + double-buffered f16 slab (2 and 4:
+    // LayerNorm-folded epilogues only).  Default: QKV 4, c_fc 2, residual 1 -- measured in the loop (TF/s, one box): QKV 942 (1) /
+    // 929 (2) / 972 (4); c_fc 870 (1) / 892 (2) / 872 (4); residual 1 007 (1) / 954 (2).  GRIP_GEMM_EMODE=<m> forces one mode,
+    // three digits one each for QKV / c_fc / residual (developer A/B).
+    static const int emode_env = getenv("GRIP_GEMM_EMODE") ? atoi(getenv("GRIP_GEMM_EMODE")) : 421;
     int emode = emode_env < 100 ? emode_env : (epi == EPI_LNFOLD_F16 ? emode_env / 100 : epi == EPI_LNFOLD_GELU_F16 ? (emode_env / 10) % 10 : emode_env % 10);
-    if (epi == EPI_BIAS_RESID_STATS && emode == 2) emode = 1;
+    if (epi == EPI_BIAS_RESID_STATS && (emode == 2 || emode == 4)) emode = 1;
+    if (emode == 4 && a.out2) emode = 1;      // the f16-slab form has no pre-activation copy (train-mode forwards)
     if (emode != 0 && (epi == EPI_LNFOLD_F16 || epi == EPI_LNFOLD_GELU_F16 || epi == EPI_BIAS_RESID_STATS)) {
-        if (emode == 2) {
+        if (emode == 4 && epi != EPI_BIAS_RESID_STATS) {
+            switch (epi) {
+                GRIP_GEMM_CASE_M(EPI_LNFOLD_F16, 4)
+                GRIP_GEMM_CASE_M(EPI_LNFOLD_GELU_F16, 4)
+            }
+        } else if (emode == 2) {
             switch (epi) {
                 GRIP_GEMM_CASE_M(EPI_LNFOLD_F16, 2)
                 GRIP_GEMM_CASE_M(EPI_LNFOLD_GELU_F16, 2)
