@@ -983,7 +983,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
 // buffers: they are 16-row, 4 KiB, swizzled slabs in the 32 KiB of LDS beside the two 64 KiB stages.
 // EMODE: 0 = 8-byte-store slab epilogue (every epilogue), 1 = 16-byte-store slab epilogue, 2 = direct epilogue with permuted W
 // fragment rows (1 and 2: the three f16-output epilogues of the pool encode).
-template <int EPI, int EMODE = 0>
+template <int EPI, int EMODE = 0, bool SD = false>
 __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m, int tiles_n, int colgroup) {
     constexpr int BMT = 256, BNT = 256, NW = 8, WN = 4;
     constexpr int STAGE = (BMT + BNT) * BK;       // halfs per stage (BK = 64)
@@ -1150,11 +1150,39 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) stage(buf, src_cur, kt + 2);
-            else if (has_next) stage(buf, src_next, kt + 2 - nk);     // the next tile's first two stages
-            if (kt + 1 < nk) load_frags(0, buf ^ 1, 0);
-            mfma_set(1);
-            spread();
+            if constexpr (SD) {
+                // Sub-step 1 as ONE basic block, so that the scheduler can place the stage's 8 DMA pieces and the 12 fragment reads
+                // BETWEEN the 32 MFMAs (as three separate blocks -- the branchy form below -- they are a DMA burst, then a read
+                // burst, then the MFMAs, and both waves of a SIMD sit in their bursts at the same time).  Unconditional: the last
+                // two stages of a workgroup's last tile re-stage the current tile's first K slice into a dead slot, and the last
+                // stage's fragment reads fetch the next tile's first fragments early (dead when there is no next tile).
+                const half_t* sp = kt + 2 < nk ? src_cur + (size_t)(kt + 2) * BK : (has_next ? src_next + (size_t)(kt + 2 - nk) * BK : src_cur);
+                half_t* dst = lds2 + buf * STAGE + r0 * BK;
+                const half_t* st = lds2 + (buf ^ 1) * STAGE;
+                // program order = the intended issue order (LDS reads and LDS-DMA writes may alias as far as the compiler knows, so it
+                // keeps their order): 2 MFMAs, 1 fragment read, 1 DMA piece, ...
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int mi = (2 * q + h) >> 2, mj = (2 * q + h) & 3;
+                        acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[1][mj], fa[1][mi], acc[mi][mj], 0, 0, 0);
+                    }
+                    if (q < 4) fb[0][q] = *(const half8*)(st + b_off[0] + q * BJ * BK);
+                    else if (q < 12) fa[0][q - 4] = *(const half8*)(st + a_off[0] + (q - 4) * 16 * BK);
+                    if (q < GI)
+                        __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)q * 8 * K + schunk[(q >> 1) & 1]), (AS3 void*)(dst + q * 8 * BK), 16, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (q < GI) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+            } else {
+                if (kt + 2 < nk) stage(buf, src_cur, kt + 2);
+                else if (has_next) stage(buf, src_next, kt + 2 - nk);     // the next tile's first two stages
+                if (kt + 1 < nk) load_frags(0, buf ^ 1, 0);
+                mfma_set(1);
+                spread();
+            }
         }
         if constexpr (EMODE == 4)
             epilogue_rows8h<EPI, true>(g, acc, (half_t*)slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
@@ -1369,6 +1397,24 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
     int emode = emode_env < 100 ? emode_env : (epi == EPI_LNFOLD_F16 ? emode_env / 100 : epi == EPI_LNFOLD_GELU_F16 ? (emode_env / 10) % 10 : emode_env % 10);
     if (epi == EPI_BIAS_RESID_STATS && (emode == 2 || emode == 4)) emode = 1;
     if (emode == 4 && a.out2) emode = 1;      // the f16-slab form has no pre-activation copy (train-mode forwards)
+    // single-block sub-step 1 (DMA pieces and fragment reads between the MFMAs) for the three default pool-encode instantiations:
+    // loop +0.9 %, residual GEMM 987 -> 1 010 TF/s, QKV 954 -> 966; GRIP_GEMM_SD=0 = the branchy form (developer A/B)
+    static const bool sd = !(getenv("GRIP_GEMM_SD") && atoi(getenv("GRIP_GEMM_SD")) == 0);
+#define GRIP_GEMM_CASE_SD(E, MODE)                                                                                          \
+    {                                                                                                                       \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64p_kernel<E, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_k64p_kernel<E, MODE, true>), grid, block, lds, s, a, tiles_m, tiles_n, colgroup);                    \
+        GRIP_CHECK_HIP(hipGetLastError());                                                                                  \
+        return GRIP_OK;                                                                                                     \
+    }
+    if (sd && epi == EPI_LNFOLD_F16 && emode == 4) GRIP_GEMM_CASE_SD(EPI_LNFOLD_F16, 4)
+    if (sd && epi == EPI_LNFOLD_GELU_F16 && emode == 2) GRIP_GEMM_CASE_SD(EPI_LNFOLD_GELU_F16, 2)
+    if (sd && epi == EPI_BIAS_RESID_STATS && emode == 1) GRIP_GEMM_CASE_SD(EPI_BIAS_RESID_STATS, 1)
+#undef GRIP_GEMM_CASE_SD
     if (emode != 0 && (epi == EPI_LNFOLD_F16 || epi == EPI_LNFOLD_GELU_F16 || epi == EPI_BIAS_RESID_STATS)) {
         if (emode == 4 && epi != EPI_BIAS_RESID_STATS) {
             switch (epi) {
