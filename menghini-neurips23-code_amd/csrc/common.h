@@ -154,7 +154,7 @@ struct GemmArgs {
     float scalar;
     int f32;            // 1 = exact mode: A, W, resid and every activation output are f32 (gemm_f32.hip, v_mfma_f32_16x16x4_f32)
     // LayerNorm statistics travelling with the residual stream (f16 towers):
-    float* stat_part;      // EPI_BIAS_RESID, optional: [M, N/64, 2] per-row partial (sum, sum of squares) of the values written, one pair
+    float* stat_part;      // EPI_BIAS_RESID, optional: [N/64, M, 2] per-row partial (sum, sum of squares) of the values written, one pair
                            // per 64-column wave tile; ln_stats_finalize turns them into rowstat for the consuming GEMM
     const float* rowstat;  // EPI_LNFOLD_*: [M, 2] (mean, rstd) of A's rows
     const float* colsum;   // EPI_LNFOLD_*: [N]

@@ -156,7 +156,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                     const float sm = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
                     const float sq = row16_sum(__builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3]))));
                     if ((lane & 15) == 0 && (!CHECK || row < g.M))
-                        ((float2*)g.stat_part)[(uint32_t)row * (uint32_t)(g.N >> 6) + (uint32_t)(col0 >> 6)] = make_float2(sm, sq);   // M * N / 64 < 2^31
+                        ((float2*)g.stat_part)[(uint32_t)(col0 >> 6) * (uint32_t)g.M + (uint32_t)row] = make_float2(sm, sq);   // [N / 64][M]: M * N / 64 < 2^31
                 }
             }
             float2 stp = make_float2(0.f, 0.f);
@@ -286,7 +286,7 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
                 sq = __builtin_fmaf(v[1][0], v[1][0], __builtin_fmaf(v[1][1], v[1][1], __builtin_fmaf(v[1][2], v[1][2], __builtin_fmaf(v[1][3], v[1][3], sq))));
                 sq = row8_sum(sq);
                 if (c8 == 0 && (!CHECK || row < g.M))
-                    ((float2*)g.stat_part)[(uint32_t)row * (uint32_t)(g.N >> 6) + (uint32_t)(col0 >> 6)] = make_float2(sm, sq);
+                    ((float2*)g.stat_part)[(uint32_t)(col0 >> 6) * (uint32_t)g.M + (uint32_t)row] = make_float2(sm, sq);       // 8 rows = 64 contiguous bytes per store
             }
             float2 st = make_float2(0.f, 0.f);
             if constexpr (FOLD) {

@@ -281,15 +281,16 @@ int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int
 // ------------------------------------------------------------------------------------------------
 // LayerNorm folded into its consumer GEMM (EPI_LNFOLD_*, gemm.hip).
 // (1) Row statistics: the residual GEMM epilogues emit, per row and 64-column wave tile, (sum, sum of squares) of the values they
-//     store; one thread per row adds the d/64 pairs in a fixed order and turns them into (mean, rstd).  96 B in, 8 B out per row
+//     store, laid out [d/64][M] (a store instruction of the epilogue writes the pairs of 8 consecutive rows = 64 contiguous bytes; the
+//     row-major layout scattered them over 8 lines); one thread per row adds the d/64 pairs in a fixed order and turns them into (mean, rstd).  96 B in, 8 B out per row
 //     at d = 768 -- against 2 x 1 536 B for a stand-alone LayerNorm pass over the stream.
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int parts, float* __restrict__ rowstat, int M, float inv_d) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= M) return;
-    const float2* p = (const float2*)part + (size_t)row * parts;
+    const float2* p = (const float2*)part + row;         // [parts][M]: consecutive threads read consecutive pairs
     float sm = 0.f, sq = 0.f;
     for (int i = 0; i < parts; ++i) {
-        const float2 v = p[i];
+        const float2 v = p[(size_t)i * M];
         sm += v.x;
         sq += v.y;
     }

@@ -167,7 +167,7 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     half_t* row_att = nullptr; // [Bp, d] LayerNorm output, [Bp, 4d] MLP hidden
     half_t* row_xn = nullptr;
     half_t* row_h = nullptr;
-    float* stat_part = nullptr;// [Mp, d/64, 2] partial row sums emitted by the residual GEMM epilogues (f16 towers)
+    float* stat_part = nullptr;// [d/64, M, 2] partial row sums emitted by the residual GEMM epilogues (f16 towers)
     float* rowstat = nullptr;  // [Mp, 2] (mean, rstd) of the residual stream's rows, consumed by the LayerNorm-folded GEMMs
     // train-mode saves, one per layer (x_in has layers+1 entries)
     std::vector<resid_t*> x_in, x_mid;

@@ -198,11 +198,11 @@ def test_layernorm_folded_into_gemm(M, d, N2, variant):
     # (1) residual epilogue + statistics
     x = torch.full((Mp, d), float("nan"), device="cuda", dtype=torch.float16)
     parts = d // 64
-    stat = torch.full((M, parts, 2), float("nan"), device="cuda")
+    stat = torch.full((parts, M, 2), float("nan"), device="cuda")         # [d / 64][M]: one (sum, sum of squares) pair per row and 64-column tile
     native.check(lib.grip_debug_gemm_ln(3, _p(A), _p(W1), M, d, d, _p(b1), _p(resid), _p(x), None, _p(stat), None, None, Mp, variant, _stream()))
     ref_x32 = A[:M].float() @ W1.float().t() + b1 + resid.float()
     torch.testing.assert_close(x[:M].float(), ref_x32, rtol=2e-3, atol=2e-3)
-    tiles = ref_x32.reshape(M, parts, 64)
+    tiles = ref_x32.reshape(M, parts, 64).transpose(0, 1)
     torch.testing.assert_close(stat[..., 0], tiles.sum(-1), rtol=1e-3, atol=2e-2)
     torch.testing.assert_close(stat[..., 1], (tiles ** 2).sum(-1), rtol=1e-3, atol=5e-2)
     # (2) finalize + folded weights
