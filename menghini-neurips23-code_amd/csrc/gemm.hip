@@ -34,6 +34,16 @@
 // the activation is a third of the c_fc GEMM's time otherwise.
 #define QGELU_C (-1.702f * 1.4426950408889634f)   // exp(-1.702 x) = exp2(QGELU_C x): one multiply in front of v_exp_f32
 __device__ __forceinline__ float quick_gelu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(QGELU_C * x)); }
+// Four at a time with the three full-rate operations as vector expressions: they compile to v_pk_mul_f32 / v_pk_add_f32 (two values
+// per instruction); written per scalar the transcendental builtins in the middle keep the compiler from packing them (c_fc's
+// epilogue: 128 elements per lane and tile, 5 VALU issues each -> 3.5).
+__device__ __forceinline__ f32x4 quick_gelu4(f32x4 x) {
+    const f32x4 t = x * QGELU_C;
+    f32x4 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+    e = e + 1.0f;
+    const f32x4 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1]), __builtin_amdgcn_rcpf(e[2]), __builtin_amdgcn_rcpf(e[3])};
+    return x * r;
+}
 __device__ __forceinline__ float quick_gelu_grad(float x) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(QGELU_C * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
@@ -178,7 +188,8 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_BIAS_GELU_F16) {
                     if (g.out2) *(half4*)((half_t*)g.out2 + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)quick_gelu(v[0]), (half_t)quick_gelu(v[1]), (half_t)quick_gelu(v[2]), (half_t)quick_gelu(v[3])};
+                    const f32x4 gv = quick_gelu4(v);
+                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)gv[0], (half_t)gv[1], (half_t)gv[2], (half_t)gv[3]};
                 } else if constexpr (FOLD) {
                     float2 st;
                     if constexpr (PRE) st = stp;
@@ -186,7 +197,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                     v = (v - csum * st.x) * st.y + bfold;
                     if constexpr (EPI == EPI_LNFOLD_GELU_F16) {
                         if (g.out2) *(half4*)((half_t*)g.out2 + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        v = (f32x4){quick_gelu(v[0]), quick_gelu(v[1]), quick_gelu(v[2]), quick_gelu(v[3])};
+                        v = quick_gelu4(v);
                     }
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_GELUGRAD_F16) {
@@ -310,7 +321,7 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
                             *(half8*)((half_t*)g.out2 + o) = (half8){(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
                                                                     (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) v[h] = (f32x4){quick_gelu(v[h][0]), quick_gelu(v[h][1]), quick_gelu(v[h][2]), quick_gelu(v[h][3])};
+                        for (int h = 0; h < 2; ++h) v[h] = quick_gelu4(v[h]);
                     }
                 }
                 *(half8*)((half_t*)g.out + o) = (half8){(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
@@ -370,7 +381,7 @@ __device__ __forceinline__ void epilogue_rows8h_impl(const GemmArgs& g, f32x4 (&
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 v = (acc[p][j] - csum[j] * st.x) * st.y + bfold[j];
-            if constexpr (EPI == EPI_LNFOLD_GELU_F16) v = (f32x4){quick_gelu(v[0]), quick_gelu(v[1]), quick_gelu(v[2]), quick_gelu(v[3])};
+            if constexpr (EPI == EPI_LNFOLD_GELU_F16) v = quick_gelu4(v);
             *(half4*)(buf + wrow + (((j * 2 + (fgrp >> 1)) ^ wx) * 8) + whalf) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         }
     };
@@ -449,7 +460,7 @@ __device__ __forceinline__ void epilogue_direct_impl(const GemmArgs& g, f32x4 (&
                     *(half8*)((half_t*)g.out2 + o + 8) = pack8(v[2], v[3]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (f32x4){quick_gelu(v[j][0]), quick_gelu(v[j][1]), quick_gelu(v[j][2]), quick_gelu(v[j][3])};
+                for (int j = 0; j < 4; ++j) v[j] = quick_gelu4(v[j]);
             }
             *(half8*)((half_t*)g.out + o) = pack8(v[0], v[1]);
             *(half8*)((half_t*)g.out + o + 8) = pack8(v[2], v[3]);
