@@ -1056,24 +1056,28 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     // EMODE 0 / 1).  EMODE 2 reads the W fragments through the row permutation of epilogue_direct, under which the eight rows a
     // fragment read touches per LDS cycle are {a * 16 + j * 4 + b: a in 0..1, b in 0..3}: key = (row & 3) | ((row >> 4) & 1) << 2
     // keeps those reads conflict-free.  A wave's 64 staged rows are rows i * 8 + srow of a 64-row block, so bit 4 is (i >> 1) & 1.
-    int schunk[2];
+    // Addresses of the DMA pieces: a wave-UNIFORM 64-bit base (tile, K slice, piece: scalar registers and scalar adds) plus a 32-bit
+    // per-lane offset that never changes (row srow of the piece, swizzled chunk) -- the saddr + voffset form of global_load_lds.  With
+    // per-lane 64-bit pointers every piece cost two 64-bit vector adds (16 VALU issues per stage and wave, between the MFMAs).
+    uint32_t lane_off[2];       // in bytes (the builtin is still selected with a 64-bit vector address: one v_lshl_add_u64 per piece from the scalar
+                                // base; the saddr form written as inline asm measured the same, so the compiler-visible builtin stays)
     if (EMODE == 2 && r0 >= BMT) {
-        schunk[0] = ((lane & 7) ^ (srow & 3)) * 8;
-        schunk[1] = schunk[0] ^ 32;
+        lane_off[0] = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(((lane & 7) ^ (srow & 3)) * 8));
+        lane_off[1] = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)((((lane & 7) ^ (srow & 3)) * 8) ^ 32));
     } else {
-        schunk[0] = schunk[1] = ((lane & 7) ^ srow) * 8;
+        lane_off[0] = lane_off[1] = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(((lane & 7) ^ srow) * 8));
     }
-    auto tile_src = [&](int tile) {
+    auto tile_src = [&](int tile) {         // uniform: first staged row of this wave in the tile's A or W panel
         int tm, tn;
         tile_coords(tile, tm, tn);
-        return r0 < BMT ? (const half_t*)g.A + (size_t)(tm * BMT + r0 + srow) * K : (const half_t*)g.W + (size_t)(tn * BNT + r0 - BMT + srow) * K;
+        return r0 < BMT ? (const half_t*)g.A + (size_t)(tm * BMT + r0) * K : (const half_t*)g.W + (size_t)(tn * BNT + r0 - BMT) * K;
     };
     auto stage = [&](int buf, const half_t* src, int kt) {
         half_t* dst = lds2 + buf * STAGE + r0 * BK;
         const half_t* sp = src + (size_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < GI; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)i * 8 * K + schunk[(i >> 1) & 1]), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(sp + (size_t)i * 8 * K) + lane_off[(i >> 1) & 1]), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -1182,7 +1186,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
                     if (q < 4) fb[0][q] = *(const half8*)(st + b_off[0] + q * BJ * BK);
                     else if (q < 12) fa[0][q - 4] = *(const half8*)(st + a_off[0] + (q - 4) * 16 * BK);
                     if (q < GI)
-                        __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)q * 8 * K + schunk[(q >> 1) & 1]), (AS3 void*)(dst + q * 8 * BK), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(sp + (size_t)q * 8 * K) + lane_off[(q >> 1) & 1]), (AS3 void*)(dst + q * 8 * BK), 16, 0, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                     if (q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (q < GI) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
