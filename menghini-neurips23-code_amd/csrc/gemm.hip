@@ -510,8 +510,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
-    const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + wave * (BMT / 4) + srow) * K + schunk * 8;
-    const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * 32 + srow) * K + schunk * 8;
+    // (wave-uniform bases + one constant 32-bit byte offset per lane: see gemm_k64p_kernel)
+    const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + wave * (BMT / 4)) * K;
+    const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * 32) * K;
+    const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
 
     auto stage = [&](int buf, int kt) {
         half_t* abase = lds + buf * STAGE + wave * (BMT / 4) * BK;
@@ -520,11 +522,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
         const half_t* ws = w_src + (size_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 8 * K), (AS3 void*)(abase + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(as + (size_t)i * 8 * K) + lane_off), (AS3 void*)(abase + i * 8 * BK), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 8 * K), (AS3 void*)(bbase + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(ws + (size_t)i * 8 * K) + lane_off), (AS3 void*)(bbase + i * 8 * BK), 16, 0, 0);
         }
     };
 
@@ -607,8 +609,10 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
-    const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + wave * 16 + srow) * K + schunk * 8;
-    const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * 32 + srow) * K + schunk * 8;
+    // (wave-uniform bases + one constant 32-bit byte offset per lane: see gemm_k64p_kernel)
+    const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + wave * 16) * K;
+    const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * 32) * K;
+    const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
 
     auto stage = [&](int buf, int kt) {
         half_t* abase = lds2 + buf * STAGE + wave * 16 * BK;
@@ -617,10 +621,10 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
         const half_t* ws = w_src + (size_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 8 * K), (AS3 void*)(abase + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(as + (size_t)i * 8 * K) + lane_off), (AS3 void*)(abase + i * 8 * BK), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 8 * K), (AS3 void*)(bbase + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(ws + (size_t)i * 8 * K) + lane_off), (AS3 void*)(bbase + i * 8 * BK), 16, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -719,8 +723,9 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     const int srow = lane >> 2;
     const int schunk = (lane & 3) ^ ((0x1320 >> (((lane >> 4) & 3) * 4)) & 3);
     const size_t K = (size_t)g.K;
-    const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + wave * GA * 16 + srow) * K + schunk * 8;
-    const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * GB * 16 + srow) * K + schunk * 8;
+    const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + wave * GA * 16) * K;
+    const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * GB * 16) * K;
+    const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
 
     auto stage = [&](int buf, int kt) {
         half_t* abase = lds2 + buf * STAGE + wave * GA * 16 * BK2;
@@ -729,10 +734,10 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
         const half_t* ws = w_src + (size_t)kt * BK2;
 #pragma unroll
         for (int i = 0; i < GA; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 16 * K), (AS3 void*)(abase + i * 16 * BK2), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(as + (size_t)i * 16 * K) + lane_off), (AS3 void*)(abase + i * 16 * BK2), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < GB; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 16 * K), (AS3 void*)(bbase + i * 16 * BK2), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(ws + (size_t)i * 16 * K) + lane_off), (AS3 void*)(bbase + i * 16 * BK2), 16, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -913,13 +918,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
     const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
     const int r0 = wave * GI * 8;                 // uniform: this wave's rows are all A rows or all W rows (GI*8 divides 256)
-    const half_t* src = (r0 < BMT ? (const half_t*)g.A + (size_t)(m0 + r0 + srow) * K : (const half_t*)g.W + (size_t)(n0 + r0 - BMT + srow) * K) + schunk * 8;
+    const half_t* src = r0 < BMT ? (const half_t*)g.A + (size_t)(m0 + r0) * K : (const half_t*)g.W + (size_t)(n0 + r0 - BMT) * K;
+    const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
     auto stage = [&](int buf, int kt) {
         half_t* dst = lds2 + buf * STAGE + r0 * BK;
         const half_t* sp = src + (size_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < GI; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(sp + (size_t)i * 8 * K), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(sp + (size_t)i * 8 * K) + lane_off), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
