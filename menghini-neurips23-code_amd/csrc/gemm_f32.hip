@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
-    const float* a_src = (const float*)g.A + (size_t)(m0 + wave * 32 + srow) * K + schunk * 4;
-    const float* w_src = (const float*)g.W + (size_t)(n0 + wave * 32 + srow) * K + schunk * 4;
+    // (wave-uniform bases + one constant 32-bit byte offset per lane, as in gemm.hip: no 64-bit vector adds per DMA piece)
+    const float* a_src = (const float*)g.A + (size_t)(m0 + wave * 32) * K;
+    const float* w_src = (const float*)g.W + (size_t)(n0 + wave * 32) * K;
+    const uint32_t lane_off = 4u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 4));
     auto stage = [&](int buf, int kt) {
         float* abase = lds + buf * STAGE_F + wave * 32 * BKF;
         float* bbase = lds + buf * STAGE_F + 128 * BKF + wave * 32 * BKF;
@@ -53,10 +55,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
         const float* ws = w_src + (size_t)kt * BKF;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)i * 8 * K), (AS3 void*)(abase + i * 8 * BKF), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(as + (size_t)i * 8 * K) + lane_off), (AS3 void*)(abase + i * 8 * BKF), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)i * 8 * K), (AS3 void*)(bbase + i * 8 * BKF), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(ws + (size_t)i * 8 * K) + lane_off), (AS3 void*)(bbase + i * 8 * BKF), 16, 0, 0);
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
