@@ -20,9 +20,15 @@
 // (relative rate) x (fill of the last wave of workgroups).
 #include <stdlib.h>
 
-#include <type_traits>
 
 #include "common.h"
+
+// Sub-step 1 of the persistent GEMM places its 12 fragment reads after MFMA pairs GRIP_RD0 .. GRIP_RD0 + 11 of the 16.  The compiler
+// puts a second s_waitcnt lgkmcnt(0) before the fifth MFMA of the block; with the reads starting at pair 0 that wait also drains the
+// two reads just issued.  Starting at pair 4 nothing newer is outstanding there: residual GEMM 1 038 -> 1 047 TF/s (0: 1 038, 2: 1 037).
+#ifndef GRIP_RD0
+#define GRIP_RD0 4
+#endif
 
 #define BM 128
 #define BN 128
@@ -1180,6 +1186,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
                 const half_t* sp = kt + 2 < nk ? src_cur + (size_t)(kt + 2) * BK : (has_next ? src_next + (size_t)(kt + 2 - nk) * BK : src_cur);
                 half_t* dst = lds2 + buf * STAGE + r0 * BK;
                 const half_t* st = lds2 + (buf ^ 1) * STAGE;
+                constexpr int RD0 = GRIP_RD0;     // first of the 16 MFMA pairs after which a fragment read is placed
                 // program order = the intended issue order (LDS reads and LDS-DMA writes may alias as far as the compiler knows, so it
                 // keeps their order): 2 MFMAs, 1 fragment read, 1 DMA piece, ...
 #pragma unroll
@@ -1189,12 +1196,12 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
                         const int mi = (2 * q + h) >> 2, mj = (2 * q + h) & 3;
                         acc[mi][mj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[1][mj], fa[1][mi], acc[mi][mj], 0, 0, 0);
                     }
-                    if (q < 4) fb[0][q] = *(const half8*)(st + b_off[0] + q * BJ * BK);
-                    else if (q < 12) fa[0][q - 4] = *(const half8*)(st + a_off[0] + (q - 4) * 16 * BK);
+                    if (q >= RD0 && q < RD0 + 4) fb[0][q - RD0] = *(const half8*)(st + b_off[0] + (q - RD0) * BJ * BK);
+                    else if (q >= RD0 + 4 && q < RD0 + 12) fa[0][q - RD0 - 4] = *(const half8*)(st + a_off[0] + (q - RD0 - 4) * 16 * BK);
                     if (q < GI)
                         __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(sp + (size_t)q * 8 * K) + lane_off[(q >> 1) & 1]), (AS3 void*)(dst + q * 8 * BK), 16, 0, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    if (q < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (q >= RD0 && q < RD0 + 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     if (q < GI) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                 }
             } else {
