@@ -29,6 +29,9 @@
 #ifndef GRIP_RD0
 #define GRIP_RD0 4
 #endif
+#ifndef GRIP_KROT
+#define GRIP_KROT 1
+#endif
 
 #define BM 128
 #define BN 128
@@ -1132,9 +1135,23 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     };
 
     const int nk = g.K / BK;    // >= 2 (checked by the launcher)
+    // K rotation: the tile of column panel tn walks its K slices cyclically from slice (tn * nk) / tiles_n.  The column tiles of one row
+    // panel run side by side on an XCD and would otherwise ask for the SAME slice of their shared A panel at the same moment -- every one
+    // of them then waits out the HBM / Infinity-Cache latency of every slice; rotated, a slice is fetched by one tile and found in the
+    // L2 by the others.  The start depends on the column panel only, so an output element's summation order does not depend on where
+    // its row sits in the launch (rows stay bit-identical under any chunking / sharding).
+    auto tile_rot = [&](int tile) {
+        int tm, tn;
+        tile_coords(tile, tm, tn);
+        if (GRIP_KROT == 0) return 0;
+        if (tiles_n >= 6) return (tn * nk) / tiles_n;           // the XCD's 32 tiles span few row panels: every slice stays in the L2 for the followers
+        return GRIP_KROT == 2 ? (tn * 2) % nk : 0;             // narrow outputs (N = 768: ~11 row panels of A in flight per XCD, more than the L2 holds)
+    };
+    auto ks = [&](int k, int rot) { return k + rot < nk ? k + rot : k + rot - nk; };
     const half_t* src_cur = tile_src(t);
-    stage(0, src_cur, 0);
-    stage(1, src_cur, 1);
+    int rot_cur = tile_rot(t);
+    stage(0, src_cur, ks(0, rot_cur));
+    stage(1, src_cur, ks(1, rot_cur));
     wait_vmcnt<GI>();
     __builtin_amdgcn_s_barrier();
     int par = 0;                // LDS slot of the current tile's stage 0
@@ -1145,6 +1162,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
         const int t_next = t + per_xcd;
         const bool has_next = t_next < xcount;
         const half_t* src_next = has_next ? tile_src(t_next) : src_cur;
+        const int rot_next = has_next ? tile_rot(t_next) : 0;
         if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_STATS) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1183,7 +1201,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
                 // burst, then the MFMAs, and both waves of a SIMD sit in their bursts at the same time).  Unconditional: the last
                 // two stages of a workgroup's last tile re-stage the current tile's first K slice into a dead slot, and the last
                 // stage's fragment reads fetch the next tile's first fragments early (dead when there is no next tile).
-                const half_t* sp = kt + 2 < nk ? src_cur + (size_t)(kt + 2) * BK : (has_next ? src_next + (size_t)(kt + 2 - nk) * BK : src_cur);
+                const half_t* sp = kt + 2 < nk ? src_cur + (size_t)ks(kt + 2, rot_cur) * BK : (has_next ? src_next + (size_t)ks(kt + 2 - nk, rot_next) * BK : src_cur);
                 half_t* dst = lds2 + buf * STAGE + r0 * BK;
                 const half_t* st = lds2 + (buf ^ 1) * STAGE;
                 constexpr int RD0 = GRIP_RD0;     // first of the 16 MFMA pairs after which a fragment read is placed
@@ -1205,8 +1223,8 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
                     if (q < GI) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                 }
             } else {
-                if (kt + 2 < nk) stage(buf, src_cur, kt + 2);
-                else if (has_next) stage(buf, src_next, kt + 2 - nk);     // the next tile's first two stages
+                if (kt + 2 < nk) stage(buf, src_cur, ks(kt + 2, rot_cur));
+                else if (has_next) stage(buf, src_next, ks(kt + 2 - nk, rot_next));     // the next tile's first two stages
                 if (kt + 1 < nk) load_frags(0, buf ^ 1, 0);
                 mfma_set(1);
                 spread();
@@ -1224,6 +1242,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
         par = (par + nk) & 1;
         t = t_next;
         src_cur = src_next;
+        rot_cur = rot_next;
     }
 }
 
