@@ -1145,7 +1145,10 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
         tile_coords(tile, tm, tn);
         if (GRIP_KROT == 0) return 0;
         if (tiles_n >= 6) return (tn * nk) / tiles_n;           // the XCD's 32 tiles span few row panels: every slice stays in the L2 for the followers
-        return GRIP_KROT == 2 ? (tn * 2) % nk : 0;             // narrow outputs (N = 768: ~11 row panels of A in flight per XCD, more than the L2 holds)
+        // narrow outputs (N = 768: ~11 row panels of A in flight per XCD, more than the L2 holds for long): a skew of ONE slice per column
+        // panel -- the follower arrives one stage after the leader's fetch has landed (residual GEMM 1 023 -> 1 040 TF/s; skews of 2 or 3
+        // slices: 1 029; the full spread: 981)
+        return tn % nk;
     };
     auto ks = [&](int k, int rot) { return k + rot < nk ? k + rot : k + rot - nk; };
     const half_t* src_cur = tile_src(t);
