@@ -889,6 +889,14 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     epilogue_rows<EPI, 8, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
+// First K slice of the tile of column panel tn (256 columns, 64-wide slices): see gemm_k64p_kernel.  The SAME rule in the
+// non-persistent 64-wide kernel, so a row's summation order is the same whichever of the two serves its launch.
+__device__ __forceinline__ int k_rot(int tn, int tiles_n, int nk) {
+    if (GRIP_KROT == 0) return 0;
+    if (tiles_n >= 6) return (tn * nk) / tiles_n;
+    return tn % nk;
+}
+
 // ---- 256x256 tile, K staged 64 wide: every DMA instruction moves 8 rows x 128 B, i.e. whole cache lines (the 32-wide
 // ring above asks the L2 for 64-byte half lines; tools/micro/dma_feed.hip: 14 TB/s vs 21 TB/s into LDS over 256 CUs).
 // Two 64 KiB stages; each stage is multiplied as two 32-wide sub-steps with register double-buffered fragments.  One
@@ -974,8 +982,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
     };
 
     const int nk = g.K / BK;    // >= 2 (checked by the launcher)
-    stage(0, 0);
-    stage(1, 1);
+    const int rot = k_rot(tn, tiles_n, nk);
+    auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
+    stage(0, ks(0));
+    stage(1, ks(1));
     wait_vmcnt<GI>();
     __builtin_amdgcn_s_barrier();
     load_frags(0, 0, 0);
@@ -989,7 +999,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage(buf, kt + 2);
+        if (kt + 2 < nk) stage(buf, ks(kt + 2));
         // sub-step 1
         if (kt + 1 < nk) load_frags(0, buf ^ 1, 0);
         mfma_set(1);
@@ -1143,12 +1153,11 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     auto tile_rot = [&](int tile) {
         int tm, tn;
         tile_coords(tile, tm, tn);
-        if (GRIP_KROT == 0) return 0;
-        if (tiles_n >= 6) return (tn * nk) / tiles_n;           // the XCD's 32 tiles span few row panels: every slice stays in the L2 for the followers
-        // narrow outputs (N = 768: ~11 row panels of A in flight per XCD, more than the L2 holds for long): a skew of ONE slice per column
+        // wide outputs (tiles_n >= 6: the XCD's 32 tiles span few row panels, every slice stays in the L2 for the followers): full spread.
+        // Narrow outputs (N = 768: ~11 row panels of A in flight per XCD, more than the L2 holds for long): a skew of ONE slice per column
         // panel -- the follower arrives one stage after the leader's fetch has landed (residual GEMM 1 023 -> 1 040 TF/s; skews of 2 or 3
         // slices: 1 029; the full spread: 981)
-        return tn % nk;
+        return k_rot(tn, tiles_n, nk);
     };
     auto ks = [&](int k, int rot) { return k + rot < nk ? k + rot : k + rot - nk; };
     const half_t* src_cur = tile_src(t);
