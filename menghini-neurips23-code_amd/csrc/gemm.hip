@@ -302,9 +302,11 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
                 v[0] += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                 v[1] += (f32x4){(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
                 const float sm = row8_sum(((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3])));
-                float sq = __builtin_fmaf(v[0][0], v[0][0], __builtin_fmaf(v[0][1], v[0][1], __builtin_fmaf(v[0][2], v[0][2], v[0][3] * v[0][3])));
-                sq = __builtin_fmaf(v[1][0], v[1][0], __builtin_fmaf(v[1][1], v[1][1], __builtin_fmaf(v[1][2], v[1][2], __builtin_fmaf(v[1][3], v[1][3], sq))));
-                sq = row8_sum(sq);
+                // (two 4-column chains added, then the tree: the same association as the 8-byte form's 16-lane reduction, so the statistics
+                // -- and with them every later value of the row -- do not depend on which kernel family serves a launch)
+                const float sqa = __builtin_fmaf(v[0][0], v[0][0], __builtin_fmaf(v[0][1], v[0][1], __builtin_fmaf(v[0][2], v[0][2], v[0][3] * v[0][3])));
+                const float sqb = __builtin_fmaf(v[1][0], v[1][0], __builtin_fmaf(v[1][1], v[1][1], __builtin_fmaf(v[1][2], v[1][2], v[1][3] * v[1][3])));
+                const float sq = row8_sum(sqa + sqb);
                 if (c8 == 0 && (!CHECK || row < g.M))
                     ((float2*)g.stat_part)[(uint32_t)(col0 >> 6) * (uint32_t)g.M + (uint32_t)row] = make_float2(sm, sq);       // 8 rows = 64 contiguous bytes per store
             }
@@ -492,6 +494,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // WMF = 16-row fragments per wave along M: 4 -> 128x128 block tile, 2 -> 64x128 (small-M problems such as the
 // training batches, where 128-row tiles leave half of the 256 CUs without a workgroup).
+// First K slice (64 wide) of a tile in the 256-column panel tn of an output with tiles_n such panels: see gemm_k64p_kernel (K rotation).
+// EVERY kernel of this file walks its K slices cyclically from this slice, so a row's summation order -- and with it every bit of the
+// result -- is the same whichever tile shape the launcher picks for the row count at hand (split-K launches excepted: they are
+// backward-only and sum their partials elsewhere).
+__device__ __forceinline__ int k_rot(int tn, int tiles_n, int nk) {
+    if (GRIP_KROT == 0) return 0;
+    if (tiles_n >= 6) return (tn * nk) / tiles_n;
+    return tn % nk;
+}
+__device__ __forceinline__ int k_rot_cols(int n0, int N, int nk) { return (N & 255) ? 0 : k_rot(n0 >> 8, N >> 8, nk); }
+
 template <int EPI, int WMF>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     constexpr int BMT = 2 * WMF * 16;
@@ -561,12 +574,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
             g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
         }
     }
-    stage(0, kt0);
+    const int rot = gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk);
+    auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
+    stage(0, kt0 + ks(0));
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of tile kt has landed (explicit: never left to the compiler)
         __syncthreads();  // tile kt visible to every wave, tile kt-1 fully read
-        if (kt + 1 < nk) stage(buf ^ 1, kt0 + kt + 1);
+        if (kt + 1 < nk) stage(buf ^ 1, kt0 + ks(kt + 1));
         const half_t* st = lds + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -656,8 +671,10 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
             g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
         }
     }
+    const int rot = gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk);
+    auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t) stage(t, kt0 + t);
+    for (int t = 0; t < NST - 1; ++t) stage(t, kt0 + ks(t));
     int buf = 0, nbuf = NST - 1;                  // slot of tile kt, slot the tile kt + NST - 1 goes to
     for (int kt = 0; kt < nk; ++kt) {
         const int younger = nk - 1 - kt;          // tiles issued after tile kt that may still be in flight (capped at NST - 2)
@@ -666,7 +683,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
         else if (NST > 3 && younger == 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();             // tile kt landed for every wave; the slot of tile kt-1 has been read by every wave
-        if (kt + NST - 1 < nk) stage(nbuf, kt0 + kt + NST - 1);
+        if (kt + NST - 1 < nk) stage(nbuf, kt0 + ks(kt + NST - 1));
         const half_t* st = lds2 + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -736,7 +753,9 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + wave * GB * 16) * K;
     const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
 
-    auto stage = [&](int buf, int kt) {
+    const int rot2 = 2 * k_rot_cols(n0, g.N, g.K / BK), nk2 = g.K / BK2;       // the shared K rotation, in 32-wide steps
+    auto stage = [&](int buf, int kt_) {
+        const int kt = kt_ + rot2 < nk2 ? kt_ + rot2 : kt_ + rot2 - nk2;
         half_t* abase = lds2 + buf * STAGE + wave * GA * 16 * BK2;
         half_t* bbase = lds2 + buf * STAGE + BMT * BK2 + wave * GB * 16 * BK2;
         const half_t* as = a_src + (size_t)kt * BK2;
@@ -887,14 +906,6 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
     // (the statistics-carrying and LayerNorm-folded epilogues hold more per-row operands: 16-row passes keep their prefetch within
     // the register budget -- with 32-row passes the 256x128 kernel spilled six dwords and returned wrong values in its last row group)
     epilogue_rows<EPI, 8, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * 64, lane);
-}
-
-// First K slice of the tile of column panel tn (256 columns, 64-wide slices): see gemm_k64p_kernel.  The SAME rule in the
-// non-persistent 64-wide kernel, so a row's summation order is the same whichever of the two serves its launch.
-__device__ __forceinline__ int k_rot(int tn, int tiles_n, int nk) {
-    if (GRIP_KROT == 0) return 0;
-    if (tiles_n >= 6) return (tn * nk) / tiles_n;
-    return tn % nk;
 }
 
 // ---- 256x256 tile, K staged 64 wide: every DMA instruction moves 8 rows x 128 B, i.e. whole cache lines (the 32-wide

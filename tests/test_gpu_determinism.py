@@ -75,3 +75,25 @@ def test_persistent_gemm_epilogue_forms_agree(tmp_path):
         assert (1 - cos).max().item() <= 1e-6, (mode, (1 - cos).max().item())
     # only the residual epilogue's statistics differ between modes 1 and 121 (c_fc direct vs slab is the same f32 arithmetic per element)
     assert torch.equal(out["121"], out["1"])
+
+
+def test_pool_encode_is_bitwise_independent_of_the_chunking():
+    """ViT-B/16 pool encode under chunkings that put the same rows into launches of very different sizes -- served by different
+    GEMM tile shapes (persistent 256x256x64 above ~220 images per launch, 128x128 / ring kernels below): every kernel of gemm.hip
+    sums a row's K slices in the same rotated order and the row statistics in the same tree, so the embeddings are bit-identical
+    (what makes a sharded pseudolabel pass reproduce the single-GPU one whatever the shard sizes are)."""
+    import grip_amd  # noqa: F401
+    from grip_amd import clip
+    m, _ = clip.load("ViT-B/16", device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(900, 3, 224, 224, device="cuda", generator=g)
+    tower = m.visual.tower
+    outs = []
+    for chunk in (900, 450, 700, 333):          # 700 -> a 200-image tail, 333 -> a 234-image tail
+        o = torch.empty(900, 512, device="cuda")
+        with torch.no_grad():
+            tower.encode_chunks(x, o, 0, 900, chunk, streams=1)
+        torch.cuda.synchronize()
+        outs.append(o.clone())
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)

@@ -14,3 +14,7 @@ for chunk in (1320, 880, 700, 2000):
     torch.cuda.synchronize()
     outs.append(o.clone())
 print('chunk invariance (bitwise):', [bool(torch.equal(outs[0], o)) for o in outs[1:]])
+for chunk, o in zip((880, 700, 2000), outs[1:]):
+    bad = (outs[0] != o).any(dim=1).nonzero().flatten()
+    if len(bad):
+        print(f"chunk {chunk}: {len(bad)} rows differ, first {int(bad[0])} last {int(bad[-1])}, max abs diff {float((outs[0] - o).abs().max()):.3e}")
