@@ -102,14 +102,46 @@ class Loop:
         self.opt = torch.optim.SGD([self.model.prefix], lr=0.1, weight_decay=0.1)
         self.graphed = steps.GraphedCoopStep(self.model, self.m, self.opt) if args.graph else None
         self.graphed_f = steps.GraphedCoopFeatureStep(self.model, self.m, self.opt) if args.graph else None
+        self.twin = self.m.exact_twin() if args.mode == "identical" else None
+        self.refine_stats = None
         self.t_pl = self.t_tr = 0.0
         self.m_selected = 0
         self.train_steps = 0
         self.last_lists = None
 
+    def identical_pass(self, streams):
+        """(i)-(iii) with the index guarantee (pseudolabels.identical_lists on this rank's resident shard): f16 encode of the
+        whole pool, head against the EXACT text features, error-bounded scan, exact re-encode of the rows it marks, until the
+        scan certifies that its lists are the fp32 scan's."""
+        a = self.args
+        with torch.no_grad():
+            txt = self.twin.encode_text(self.zs_tokens)
+            local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
+            self.m.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk, streams=streams)
+            emb = gdist.allgather_rows(local, self.n_total, a.pool)
+            scale = self.m.logit_scale.exp().item()
+            _, probs, _, am_p = engine.cosine_head(emb, txt, scale)
+            probs_h, pred_h = probs.cpu().numpy(), am_p.cpu().numpy()
+            lo = self.rank * a.pool
+            tower32 = self.twin.visual.tower
+
+            def exact_rows(idx):
+                mine = torch.from_numpy(idx[(idx >= lo) & (idx < lo + a.pool)] - lo).to(self.device)
+                rows = torch.empty(len(mine), self.d.embed_dim, dtype=torch.float32, device=self.device)
+                if len(mine):
+                    tower32.encode_chunks(lambda s, e: self.pool[mine[s:e]], rows, 0, len(mine), a.exact_chunk, streams=1)
+                rows = gdist.allgather_selected(rows, idx, self.n_total)
+                _, p, _, ap = engine.cosine_head(rows, txt, scale)
+                return p.cpu().numpy(), ap.cpu().numpy()
+
+            img, cls, self.refine_stats = pl.refine_scan(probs_h, pred_h, self.ranks, self.k, exact_rows)
+        return img, cls
+
     def pseudolabel_pass(self, model, streams):
         """(i)-(iii) with `model` (the f16 engine, or the exact one for the comparison block)."""
         a = self.args
+        if model is self.m and a.mode == "identical":
+            return self.identical_pass(streams)
         trace = os.environ.get("GRIP_BENCH_TRACE") == "1"     # developer: per-stage wall times of one pass (adds synchronisations)
         marks = [("start", time.perf_counter())]
 
@@ -192,7 +224,7 @@ N_SLOTS = 112   # slot = variant * 16 + epilogue id (csrc/gemm.hip)
 
 def kname(slot):
     v, e = divmod(slot, 16)
-    return {1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
+    return {0: f"gemm_f32_kernel<{e}>", 1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
             5: f"gemm_k64_kernel<{e}, 8>", 6: f"gemm_k64p_kernel<{e}>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e] if e < len(EPI_NAMES) else e}]"
 
 
@@ -296,27 +328,42 @@ def cpu_baseline(args):
 
 # ------------------------------------------------------------------------------------------------ exact + secondary blocks
 def exact_block(loop, lib):
-    """The fp32 comparison mode on the SAME resident pool: images/sec of its pseudolabel pass and the overlap of its
-    (image, class) pairs with the f16 engine's lists (the f16 lists differ from fp32 ones only at near-tied boundaries)."""
+    """The fp32 comparison mode on the SAME resident pool, outside the timed region: images/sec of its pseudolabel pass (every row
+    through the f32 towers); whether the timed loop's lists ARE its lists (the index guarantee of --mode identical, checked here
+    on the full pool); the same pass under a second chunking (rows must not depend on the chunk they are encoded in: lists
+    bit-for-bit); and one plain f16 pass for the rate and the overlap of the un-refined f16 lists."""
     a = loop.args
-    em, _ = clip.load(MODEL, device=loop.device, exact=True)
-    # warm-up on a small slice, then one timed pass
+    em = loop.twin if loop.twin is not None else clip.load(MODEL, device=loop.device, exact=True)[0]
     with torch.no_grad():
         em.encode_image(loop.pool[:64])
     torch.cuda.synchronize()
+    img_l, cls_l = loop.last_lists
     t0 = time.perf_counter()
     img_e, cls_e = loop.pseudolabel_pass(em, 1)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    img_h, cls_h = loop.last_lists
+    keep, a.exact_chunk = a.exact_chunk, a.exact_chunk * 3 // 2
+    img_e2, cls_e2 = loop.pseudolabel_pass(em, 1)
+    a.exact_chunk = keep
+    mode, a.mode = a.mode, "f16"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img_h, cls_h = loop.pseudolabel_pass(loop.m, a.streams)
+    torch.cuda.synchronize()
+    dt_h = time.perf_counter() - t0
+    a.mode = mode
     pe, ph = set(zip(img_e.tolist(), cls_e.tolist())), set(zip(img_h.tolist(), cls_h.tolist()))
-    del em
-    torch.cuda.empty_cache()
     return {"exact_images_per_sec": loop.n_total / dt, "pool_images": loop.n_total, "dtype": "f32",
             "achieved_tflops": loop.n_total * F_IMG / dt / 1e12, "peak_tflops": PEAK_F32_TFLOPS, "frac": loop.n_total * F_IMG / dt / 1e12 / PEAK_F32_TFLOPS,
-            "pairs_exact": len(pe), "pairs_f16": len(ph), "pair_overlap_f16_vs_exact": len(pe & ph) / max(len(pe), 1),
-            "note": "f32 weights/activations/attention (v_mfma_f32_16x16x4_f32); list equality of this mode with the fp32 oracle is asserted in "
-                    "tests/test_gpu_exact.py"}
+            "pairs_exact": len(pe),
+            "timed_loop_lists_identical_to_exact": bool(np.array_equal(img_l, img_e) and np.array_equal(cls_l, cls_e)),
+            "timed_loop_mode": mode,
+            "exact_lists_identical_under_second_chunking": bool(np.array_equal(img_e, img_e2) and np.array_equal(cls_e, cls_e2)),
+            "chunkings": [keep, keep * 3 // 2],
+            "f16_pass_images_per_sec": loop.n_total / dt_h, "pairs_f16": len(ph), "pair_overlap_f16_vs_exact": len(pe & ph) / max(len(pe), 1),
+            "f16_lists_identical_to_exact": bool(np.array_equal(img_h, img_e) and np.array_equal(cls_h, cls_e)),
+            "note": "f32 weights/activations/attention (v_mfma_f32_16x16x4_f32); list equality of this mode with the fp32 oracle / the reference's own "
+                    "outputs is asserted in tests/test_gpu_exact.py, of the identical mode with this mode in tests/test_gpu_identical.py"}
 
 
 def secondary_block(loop, lib):
@@ -411,6 +458,9 @@ def main():
                     help="CoOp steps whose frozen image-tower forward is batched into one encode (steps.lookahead_image_features); 1 = encode inside every step")
     ap.add_argument("--graph", type=int, default=1, choices=(0, 1),
                     help="1: the CoOp step's forward + backward replayed from a HIP graph captured once (steps.GraphedCoopStep); 0: eager launches")
+    ap.add_argument("--mode", default="identical", choices=("identical", "f16"),
+                    help="identical (default, what utils.pseudolabel_top_k does): the pass returns the fp32 scan's lists -- f16 encode of the pool, "
+                         "error-bounded scan, exact (f32) re-encode of the rows it marks; f16: the f16 towers' own lists (boundary items may differ)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the fp32 comparison-mode block")
     ap.add_argument("--exact-chunk", type=int, default=220)
@@ -455,6 +505,25 @@ def main():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = el.item()
     launches, ms, fl = profile_collect(lib)
+    f16_loop = None
+    if args.mode == "identical":
+        # the same loop once more WITHOUT the guarantee (the f16 towers' own lists), outside the timed region: what the index guarantee costs
+        keep = (loop.t_pl, loop.t_tr, loop.m_selected, loop.train_steps, loop.last_lists, loop.refine_stats)
+        args.mode = "f16"
+        loop.t_pl = loop.t_tr = 0.0
+        gdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.step()
+        gdist.barrier()
+        torch.cuda.synchronize()
+        el16 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if on_host else device)
+        if ws > 1:
+            torch.distributed.all_reduce(el16, op=torch.distributed.ReduceOp.MAX)
+        f16_loop = {"images_per_sec": loop.n_total / el16.item(), "pseudolabel_images_per_sec": loop.n_total / loop.t_pl, "steps": 1,
+                    "index_guarantee": "none (f16 lists: boundary items may differ from the fp32 scan's; see exact.pair_overlap_f16_vs_exact)"}
+        args.mode = "identical"
+        loop.t_pl, loop.t_tr, loop.m_selected, loop.train_steps, loop.last_lists, loop.refine_stats = keep
     if rank != 0:
         if ws > 1:
             gdist.barrier()
@@ -469,6 +538,10 @@ def main():
     executed = images * f_img_x + args.steps * args.classes * text_flops(seq_zs) * ws \
         + args.steps * loop.train_steps * ws * (args.batch * f_img_x + 2 * args.classes * text_flops(seq))
     traffic, mfma_util = pmc_entry(kname(dom))
+    peak = PEAK_F32_TFLOPS if dom < 16 else PEAK_F16_TFLOPS       # profiler variant 0 = the exact tower's f32 GEMM
+    rs = loop.refine_stats
+    if rs is not None:      # the rows the identical pass re-encoded with the f32 tower are work the engine issued on top of the algorithmic count
+        executed += args.steps * rs["rows_refined"] * F_IMG       # (the f32 tower computes the whole last block)
     out = {
         "metric": "images/sec CLIP ViT-B/16 encode+prompt-step",
         "value": images / elapsed,
@@ -478,6 +551,13 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "Flowers102-shaped CoOp textual-prompt SSL pseudolabel+prompt-step loop, ViT-B/16 (BASELINE.json configs[1])",
+                   "pseudolabel_mode": args.mode,
+                   "index_guarantee": ("`value` itself carries it: every timed pass returns the lists of the fp32 (exact-mode) scan -- f16 towers screen the pool, "
+                                       "the error-bounded scan marks the rows whose f16 probabilities cannot decide a comparison the lists depend on, "
+                                       "the f32 towers re-encode those rows, until the scan certifies its lists (pseudolabels.refine_scan; equality with the "
+                                       "exact mode on this very pool is checked in the `exact` block and asserted in tests/test_gpu_identical.py)")
+                                      if args.mode == "identical" else
+                                      "none: f16 lists (boundary items may differ from the fp32 scan's); run with --mode identical for the guarantee",
                    "pool_images_per_gpu": args.pool, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
                    "encode_chunk": args.chunk, "encode_streams": args.streams, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
                    "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps),
@@ -491,6 +571,13 @@ def main():
                                   if not on_host else "gloo through host memory (GRIP_DIST_BACKEND=gloo)"},
         "ranks_seen": seen,
         "pseudolabel_images_per_sec": images / loop.t_pl if loop.t_pl else None,
+        "identical_images_per_sec": (images / loop.t_pl if loop.t_pl else None) if args.mode == "identical" else None,
+        "f16_mode_loop": f16_loop,
+        "identical": None if rs is None else {
+            "rows_reencoded_exactly": rs["rows_refined"], "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1),
+            "calibration_rows": rs["calibration_rows"], "rounds": rs["rounds"], "scans": rs["scans"], "rows_per_round": rs["refined_per_round"],
+            "relative_bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "safety": rs["safety"],
+            "note": "last timed pass; bound = safety x the largest |p_f16 / p_f32 - 1| over every row re-encoded so far"},
         "train_images_per_sec": train_imgs / loop.t_tr if loop.t_tr else None,
         "algorithmic_tflops": nominal / elapsed / 1e12 / ws,
         "executed_tflops": executed / elapsed / 1e12 / ws,
@@ -500,7 +587,7 @@ def main():
                       "EOT cannot influence any output); results are identical either way",
         "roofline": {
             "bound": "mfma", "kernel": kname(dom),
-            "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "mfma_util_pmc": mfma_util,
             "traffic_source": f"{TRAFFIC_FILE}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES), "
                               "read from the committed file, not measured in this run",

@@ -37,7 +37,7 @@ typedef enum {
 const char* grip_last_error(void);
 /* ABI version of this header; the host layer refuses a library that reports another one. */
 int grip_abi_version(void);
-#define GRIP_ABI_VERSION 4
+#define GRIP_ABI_VERSION 5
 
 /* ------------------------------------------------------------------------------------------
  * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
@@ -217,6 +217,22 @@ int grip_preprocess_batch(const grip_preprocess_item* items_device, int n_items,
  */
 int grip_leaderboard_scan(const float* probs, const int32_t* pred, const int64_t* path_rank,
                           int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count);
+
+/* The same scan over probabilities that are only known to a per-row relative accuracy (screen and refine): rows encoded by the
+ * f16 towers carry rel_eps[i] > 0, rows re-encoded by an exact (precision = 1) tower carry 0.  Every order the reference's scan
+ * depends on (the arg-max, utils/clip_pseudolabels.py:39; `board[-1].score < score`, :75 / :95; the sorted inserts, :79-82 /
+ * :97-100) is decided on the intervals [p (1 - eps), p (1 + eps)].  ambiguous[i] is set to 1 for every row with rel_eps[i] > 0 that
+ * took part in a comparison the intervals could not decide (an undecidable arg-max only counts when one of the candidate classes
+ * could admit the image: when all of them certainly reject it the image spills to every class whichever of them is the true
+ * arg-max).  *n_ambiguous == 0  =>  the lists written are the lists grip_leaderboard_scan returns on the TRUE probabilities,
+ * provided every |p_i[j] / true_i[j] - 1| <= rel_eps[i].  Otherwise the caller re-encodes the marked rows exactly, sets their
+ * rel_eps to 0 and calls again; the marked set grows strictly, so the loop ends (host side: grip_amd.pseudolabels.refine_scan).
+ *   k == 10000000 (the reference's "label everything" branch, :27-44): out_img / out_class need capacity n and every row
+ *   whose arg-max is undecidable is marked.  Otherwise capacity c * min(k, n) as above.
+ *   ambiguous [n] uint8 host (overwritten). */
+int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps,
+                                  int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count,
+                                  uint8_t* ambiguous, int64_t* n_ambiguous);
 
 /* ------------------------------------------------------------------------------------------
  * clip.tokenize's byte-level BPE (host function; the reference tokenises on every CustomTextEncoder.forward,

@@ -109,11 +109,23 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
     else:
         _warn_once("weights", "clip.load: no $CLIP_WEIGHTS -- using SYNTHETIC seeded random-init weights (accuracies are meaningless)")
         PROVENANCE["weights"] = "synthetic"
-        if _SD_CACHE.get("key") != (name, seed):      # a second load of the same synthetic model (e.g. its exact twin) reuses the arrays
-            _SD_CACHE.update(key=(name, seed), sd=_weights.init_state_dict(d, seed))
-        sd = {k: torch.from_numpy(v) for k, v in _SD_CACHE["sd"].items()}
+        sd = {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed).items()}    # a second load of the same synthetic model reuses the arrays
     load_openai_state_dict(m, sd)
+    if not exact:
+        src = None if path is None else sd       # a checkpoint's tensors are kept for the twin; the synthetic init is regenerated
+
+        def build_twin():
+            t = CLIP(d, device, exact=True)
+            load_openai_state_dict(t, src if src is not None else {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed).items()})
+            return t
+        m._twin[1] = build_twin
     return m, _preprocess(d.image_resolution, device)
+
+
+def _synthetic_sd(name, d, seed):
+    if _SD_CACHE.get("key") != (name, seed):
+        _SD_CACHE.update(key=(name, seed), sd=_weights.init_state_dict(d, seed))
+    return _SD_CACHE["sd"]
 
 
 def load_openai_state_dict(m: CLIP, sd):

@@ -117,6 +117,18 @@ class CLIP(_TowerModule):
         self.add_module("token_embedding", _Embedding())
         self._bind(engine.text_tower(d, device, exact=exact))
         self.logit_scale = _frozen(torch.ones([], device=device) * math.log(1 / 0.07))
+        self._twin = [None, None]       # [the exact (f32) twin, a callable that builds it]: set by clip.load, out of nn.Module's registry
+
+    def exact_twin(self):
+        """The same model with f32 towers (weights from the same checkpoint, NOT re-derived from this model's f16 blobs): what
+        the screen-and-refine pseudolabel pass re-encodes its undecidable rows with.  Built on first use (ViT-B/16: 0.7 GB)."""
+        if self.exact:
+            return self
+        if self._twin[0] is None:
+            if self._twin[1] is None:
+                raise engine.native.GripError("this CLIP was not created by clip.load: no source for its exact twin")
+            self._twin[0] = self._twin[1]()
+        return self._twin[0]
 
     @property
     def text_tower(self):

@@ -1326,7 +1326,6 @@ extern "C" int grip_profile_collect(int n, int64_t* launches, double* total_ms, 
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen);
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
-    if (a.f32) return launch_gemm_f32(epi, a, s);     // exact mode: f32 operands (gemm_f32.hip)
     // sample every 4th launch: the launch sequence is periodic with an odd period (49 GEMMs per
     // encode chunk), so every kernel/shape is sampled uniformly while the markers cost < 1 %
     static unsigned g_tick = 0;
@@ -1342,7 +1341,7 @@ int launch_gemm(int epi, const GemmArgs& a, hipStream_t s) {
     (void)hipEventRecord(r.a, s);
     const int rc = launch_gemm_impl(epi, a, s, &chosen);
     (void)hipEventRecord(r.b, s);
-    r.epi = chosen * 16 + ((epi == EPI_BIAS_RESID && a.stat_part) ? (int)EPI_BIAS_RESID_STATS : epi);   // the instantiation that actually ran
+    r.epi = chosen * 16 + ((epi == EPI_BIAS_RESID && a.stat_part && !a.f32) ? (int)EPI_BIAS_RESID_STATS : epi);   // the instantiation that actually ran
     g_recs.push_back(r);
     return rc;
 }
@@ -1580,6 +1579,10 @@ static int launch_ring(int epi, const GemmArgs& a, int nst, dim3 grid, hipStream
 }
 
 static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
+    if (a.f32) {        // exact mode: f32 operands (gemm_f32.hip); profiler variant 0
+        *chosen = 0;
+        return launch_gemm_f32(epi, a, s);
+    }
     if (epi == EPI_BIAS_RESID && a.stat_part) epi = EPI_BIAS_RESID_STATS;
     GRIP_REQUIRE(epi != EPI_BIAS_RESID_STATS || (a.stat_part && a.N % 64 == 0), "gemm: row statistics need stat_part and N %% 64 == 0");
     GRIP_REQUIRE(a.N % BN == 0 && a.K % BK == 0 && a.M > 0, "gemm: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);

@@ -12,7 +12,10 @@
 // binary insertion once a board is sorted.  O(n*c) compares, no allocation inside the scan.
 // The path strings are represented by their rank among all paths (dense, equal strings share a
 // rank), computed by the host layer with Python's own string order.
+#include <stdlib.h>
+
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -84,4 +87,278 @@ extern "C" int grip_leaderboard_scan(const float* probs, const int32_t* pred, co
     *out_count = m;
     return GRIP_OK;
     } catch (...) { grip_set_error("leaderboard: out of memory"); return GRIP_ERR_ARG; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Error-bounded scan (screen and refine).  Same algorithm, but row i's probabilities are only known to a relative accuracy
+// rel_eps[i] (f16 towers; 0 = the row was re-encoded by the exact tower and is final): the true value of a score s lies in
+// [s (1 - eps), s (1 + eps)].  The scan marks the un-refined rows it would need exactly in order to PROVE that its lists are
+// the lists of the scan over the true values; the caller re-encodes them (eps = 0) and scans again.  Every round with a
+// non-empty marked set refines at least one new row, so the loop ends.
+//
+// What has to be certain (reference lines: utils/clip_pseudolabels.py):
+//  (A) the arg-max of a row (:39).  Candidates = classes whose interval reaches the largest value's.  If EVERY candidate's
+//      board is full and certainly rejects the row it does not matter which of them is the true arg-max: the image spills to
+//      every other class either way, the candidates reject it either way, the remaining classes see the same offer.
+//      Otherwise the row is marked.
+//  (B) while a board has never overflowed (unsorted append list, admission test against the LAST APPENDED element, :73-76): every
+//      `board[-1].score < score` -- a rejected offer is lost for good and the first success changes the board's regime.
+//  (C) the own-class decision of every image (:73-76 -> spill or not, :83): from the first overflow on a board is the sorted top-k
+//      of everything it was offered since, so `board[-1].score` is the k-th largest TRUE value among those offers, which lies
+//      between the k-th largest lower bound T_lo and the k-th largest upper bound T_hi of the offers.  Accept is certain when
+//      T_hi < lo(x), reject when T_lo >= hi(x); otherwise x and the un-refined offers whose intervals meet x's are marked.
+//  (D) the FINAL content and order of every board (:103-109).  Offers from other classes' spills (:83-101) need no certain
+//      decision at the time they are made: an offer whose upper bound is below T_lo can never be among the k largest (k
+//      offers are certainly above it) and is dropped; the others are recorded, and at the end the nominal board B must be
+//      (a) certainly ordered pair by pair and (b) certainly above every recorded offer outside it.  Then B holds the k largest
+//      true values, each of them was admitted when it arrived (fewer than k offers are above it) and never evicted, and the true
+//      list order is B's.  Intermediate boards may differ from the true scan's; nothing reads them except (C), which uses the
+//      bounds.  An exact tie between two FINAL (eps = 0) values across the boundary of a board is the one case this argument does not cover
+//      (the reference's outcome then depends on arrival order); the scan then falls back to the strict form, in which every single
+//      comparison of the literal algorithm is certified (mode 1 below).
+namespace {
+struct BEntry {
+    double lo, hi;      // interval of the true score
+    float score;        // nominal
+    float eps;
+    int64_t rank;
+    int32_t img;
+};
+inline BEntry make_entry(float s, float eps, int64_t rank, int32_t img) {
+    return BEntry{(double)s * (1.0 - (double)eps), (double)s * (1.0 + (double)eps), s, eps, rank, img};
+}
+// outcome of `a.score < x.score` over the true values: 1 certainly true, 0 certainly false, -1 undecidable
+inline int certainly_less(const BEntry& a, const BEntry& x) {
+    if (a.eps == 0.f && x.eps == 0.f) return a.score < x.score ? 1 : 0;
+    if (a.hi < x.lo) return 1;
+    if (a.lo >= x.hi) return 0;
+    return -1;
+}
+inline bool nominal_greater(const BEntry& a, const BEntry& b) {
+    if (a.score != b.score) return a.score > b.score;
+    return a.rank > b.rank;
+}
+// is "a sorts before b" (score descending, ties by path descending) decided?  a is nominally before b.
+inline bool order_certain(const BEntry& a, const BEntry& b) {
+    if (a.eps == 0.f && b.eps == 0.f) return true;       // both final: the nominal comparison IS the true one
+    return a.lo > b.hi;
+}
+// the k largest values seen so far (min-heap); kth() = -inf until k values were pushed
+struct TopK {
+    std::vector<double> h;
+    size_t k = 0;
+    double kth() const { return h.size() < k ? -1e300 : h.front(); }
+    void push(double v) {
+        if (h.size() < k) {
+            h.push_back(v);
+            std::push_heap(h.begin(), h.end(), std::greater<double>());
+        } else if (v > h.front()) {
+            std::pop_heap(h.begin(), h.end(), std::greater<double>());
+            h.back() = v;
+            std::push_heap(h.begin(), h.end(), std::greater<double>());
+        }
+    }
+};
+struct BBoard {
+    std::vector<BEntry> e;      // the nominal board
+    bool sorted = false;
+    TopK lo, hi;                // bounds of the true k-th largest offer since the first overflow
+    std::vector<BEntry> rec;    // offers since the first overflow that were not certainly irrelevant when they arrived
+    size_t prune_at = 0;
+};
+struct Marks {
+    uint8_t* flag;
+    int64_t count = 0;
+    inline void mark(const BEntry& x) {
+        if (x.eps != 0.f && !flag[x.img]) { flag[x.img] = 1; ++count; }
+    }
+};
+
+struct BoundedScan {
+    const float* probs; const int32_t* pred; const int64_t* path_rank; const float* rel_eps;
+    int64_t n; int c; int64_t kk; bool strict;
+    std::vector<BBoard> boards;
+    std::vector<double> t_lo;       // per class: T_lo once the board is sorted, -inf before (nothing is dropped then)
+    Marks mk;
+    bool need_strict = false;
+
+    void record(BBoard& b, int j, const BEntry& x) {
+        b.rec.push_back(x);
+        b.lo.push(x.lo);
+        b.hi.push(x.hi);
+        t_lo[(size_t)j] = b.lo.kth();
+        if (b.rec.size() >= b.prune_at) {       // forget what has become certainly irrelevant since
+            const double t = t_lo[(size_t)j];
+            size_t w = 0;
+            for (size_t r = 0; r < b.rec.size(); ++r)
+                if (!(b.rec[r].hi < t)) b.rec[w++] = b.rec[r];
+            b.rec.resize(w);
+            b.prune_at = std::max<size_t>(4 * (size_t)kk + 64, 2 * w);
+        }
+    }
+    void nominal_insert(BBoard& b, const BEntry& x) {
+        if (!(b.e.back().score < x.score)) return;
+        auto pos = std::upper_bound(b.e.begin(), b.e.end(), x, nominal_greater);
+        b.e.insert(pos, x);
+        b.e.pop_back();
+    }
+    // an offer to board j (its own class after an accept, or a spill)
+    void offer(int j, const BEntry& x) {
+        BBoard& b = boards[(size_t)j];
+        if ((int64_t)b.e.size() < kk) { b.e.push_back(x); return; }
+        if (b.sorted && !strict) {                                   // (D)
+            if (x.hi < t_lo[(size_t)j]) return;
+            record(b, j, x);
+            nominal_insert(b, x);
+            return;
+        }
+        const int lt = certainly_less(b.e.back(), x);                // (B), and every comparison in strict mode
+        if (lt < 0) { mk.mark(b.e.back()); mk.mark(x); }
+        const bool accept = lt >= 0 ? lt == 1 : b.e.back().score < x.score;
+        if (!accept) return;
+        if (!b.sorted) {
+            b.e.push_back(x);
+            std::stable_sort(b.e.begin(), b.e.end(), nominal_greater);
+            if (strict) {
+                for (size_t i = 0; i + 1 < b.e.size(); ++i)
+                    if (!order_certain(b.e[i], b.e[i + 1])) { mk.mark(b.e[i]); mk.mark(b.e[i + 1]); }
+            } else {                                                 // the k + 1 elements are the first offers of the sorted regime
+                b.lo.k = b.hi.k = (size_t)kk;
+                b.prune_at = 4 * (size_t)kk + 64;
+                for (const BEntry& y : b.e) record(b, j, y);
+            }
+            b.e.pop_back();
+            b.sorted = true;
+            return;
+        }
+        auto pos = std::upper_bound(b.e.begin(), b.e.end(), x, nominal_greater);     // strict mode, sorted board
+        if (pos != b.e.begin() && !order_certain(*(pos - 1), x)) { mk.mark(*(pos - 1)); mk.mark(x); }
+        if (pos != b.e.end() && !order_certain(x, *pos)) { mk.mark(*pos); mk.mark(x); }
+        b.e.insert(pos, x);
+        b.e.pop_back();
+    }
+    // does board j certainly reject x?  (full board required)
+    bool certainly_rejects(int j, const BEntry& x) const {
+        const BBoard& b = boards[(size_t)j];
+        if ((int64_t)b.e.size() < kk) return false;
+        if (b.sorted && !strict) return t_lo[(size_t)j] >= x.hi;
+        return certainly_less(b.e.back(), x) == 0;
+    }
+
+    int run(int32_t* out_img, int32_t* out_class, int64_t* out_count, uint8_t* ambiguous, int64_t* n_ambiguous, int64_t k) {
+        const bool label_all = k == 10000000;      // utils/clip_pseudolabels.py:27-44: every image under its arg-max, no boards
+        boards.assign((size_t)c, BBoard());
+        t_lo.assign((size_t)c, -1e300);
+        if (!label_all) for (auto& b : boards) b.e.reserve((size_t)kk + 2);
+        std::vector<int> cand;
+        cand.reserve((size_t)c);
+        memset(ambiguous, 0, (size_t)n);
+        mk = Marks{ambiguous};
+        need_strict = false;
+        for (int64_t i = 0; i < n; ++i) {
+            const float* p = probs + i * c;
+            const int js = pred[i];
+            const float eps = rel_eps[i];
+            GRIP_REQUIRE(js >= 0 && js < c, "bounded leaderboard: pred[%lld] = %d out of range", (long long)i, js);
+            GRIP_REQUIRE(eps >= 0.f && eps < 0.5f, "bounded leaderboard: rel_eps[%lld] = %g out of range", (long long)i, (double)eps);
+            const BEntry x = make_entry(p[js], eps, path_rank[i], (int32_t)i);
+            const double up = 1.0 + (double)eps;
+            cand.clear();                                                   // (A)
+            if (eps != 0.f)
+                for (int j = 0; j < c; ++j)
+                    if (j != js && (double)p[j] * up >= x.lo) cand.push_back(j);
+            if (label_all) {
+                if (!cand.empty()) mk.mark(x);
+                continue;
+            }
+            BBoard& own = boards[(size_t)js];
+            if (!cand.empty()) {
+                bool all_reject = certainly_rejects(js, x);
+                for (size_t q = 0; all_reject && q < cand.size(); ++q)
+                    all_reject = certainly_rejects(cand[q], make_entry(p[cand[q]], eps, x.rank, x.img));
+                if (!all_reject) mk.mark(x);
+            }
+            bool spill;
+            if ((int64_t)own.e.size() < kk) {
+                spill = false;
+            } else if (own.sorted && !strict) {                             // (C)
+                spill = !(own.e.back().score < x.score);
+                const bool sure_accept = own.hi.kth() < x.lo, sure_reject = t_lo[(size_t)js] >= x.hi;
+                if (!sure_accept && !sure_reject) {
+                    mk.mark(x);
+                    for (const BEntry& y : own.rec)
+                        if (y.eps != 0.f && y.lo <= x.hi && y.hi >= x.lo) mk.mark(y);
+                }
+            } else {
+                const int lt = certainly_less(own.e.back(), x);
+                if (lt < 0) { mk.mark(own.e.back()); mk.mark(x); }
+                spill = !(lt >= 0 ? lt == 1 : own.e.back().score < x.score);
+            }
+            if (!spill) {
+                offer(js, x);
+            } else {
+                for (int j = 0; j < c; ++j) {
+                    if (j == js) continue;
+                    if ((double)p[j] * up < t_lo[(size_t)j]) continue;      // the common case of (D): certainly irrelevant
+                    offer(j, make_entry(p[j], eps, x.rank, x.img));
+                }
+            }
+        }
+        if (!label_all && !strict) {                                        // (D): certify the final boards
+            std::vector<uint8_t> in_board((size_t)std::max<int64_t>(n, 1), 0);
+            for (int j = 0; j < c; ++j) {
+                BBoard& b = boards[(size_t)j];
+                if (!b.sorted) continue;
+                for (size_t i = 0; i + 1 < b.e.size(); ++i)
+                    if (!order_certain(b.e[i], b.e[i + 1])) { mk.mark(b.e[i]); mk.mark(b.e[i + 1]); }
+                for (const BEntry& y : b.e) in_board[(size_t)y.img] = 1;
+                const BEntry& last = b.e.back();
+                const double t = t_lo[(size_t)j];
+                for (const BEntry& y : b.rec) {
+                    if (y.hi < t || in_board[(size_t)y.img]) continue;
+                    if (y.eps == 0.f && last.eps == 0.f) {
+                        if (!(y.score < last.score)) need_strict = true;    // an exact tie of two final values across the boundary
+                    } else if (!(y.hi < last.lo)) {
+                        mk.mark(last);
+                        if (last.eps == 0.f || y.hi >= (double)last.score) mk.mark(y);   // the rest waits until `last` is final
+                    }
+                }
+                for (const BEntry& y : b.e) in_board[(size_t)y.img] = 0;
+            }
+        }
+        int64_t m = 0;
+        if (label_all) {
+            for (int64_t i = 0; i < n; ++i) { out_img[m] = (int32_t)i; out_class[m] = pred[i]; ++m; }
+        } else {
+            for (int j = 0; j < c; ++j)
+                for (const BEntry& e : boards[(size_t)j].e) {
+                    out_img[m] = e.img;
+                    out_class[m] = j;
+                    ++m;
+                }
+        }
+        *out_count = m;
+        *n_ambiguous = mk.count;
+        return GRIP_OK;
+    }
+};
+}  // namespace
+
+extern "C" int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps,
+                                             int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count,
+                                             uint8_t* ambiguous, int64_t* n_ambiguous) {
+    GRIP_REQUIRE(probs && pred && path_rank && rel_eps && out_img && out_class && out_count && ambiguous && n_ambiguous, "bounded leaderboard: null pointer");
+    GRIP_REQUIRE(n >= 0 && c > 0 && k > 0, "bounded leaderboard: bad sizes n=%lld c=%d k=%lld", (long long)n, c, (long long)k);
+    try {
+        BoundedScan s{probs, pred, path_rank, rel_eps, n, c, std::min<int64_t>(k, std::max<int64_t>(n, 1)), false};
+        const char* env = getenv("GRIP_SCAN_STRICT");       // developer A/B: certify every comparison of the literal algorithm
+        s.strict = env && env[0] == '1';
+        int rc = s.run(out_img, out_class, out_count, ambiguous, n_ambiguous, k);
+        if (rc == GRIP_OK && s.need_strict && *n_ambiguous == 0) {
+            if (getenv("GRIP_SCAN_DEBUG")) fprintf(stderr, "strict-fallback\n");
+            s.strict = true;
+            rc = s.run(out_img, out_class, out_count, ambiguous, n_ambiguous, k);
+        }
+        return rc;
+    } catch (...) { grip_set_error("bounded leaderboard: out of memory"); return GRIP_ERR_ARG; }
 }

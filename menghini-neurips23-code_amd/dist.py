@@ -136,6 +136,26 @@ def allgather_rows(local, n_total, per):
     return out[:n_total]
 
 
+def allgather_selected(local_rows, idx, n_total):
+    """Rows of a scattered selection of the pool on every rank.  `idx`: ascending global row numbers, the same array on every
+    rank (the rows a screen-and-refine scan asked for); `local_rows` [m_r, E]: this rank's rows of `idx` that fall into its
+    contiguous shard (shard_range), in order.  Returns [len(idx), E] in the order of `idx`.  One all-gather, padded to the
+    largest per-rank count."""
+    import numpy as np
+    rank, ws = world()
+    if ws == 1:
+        return local_rows
+    per = (n_total + ws - 1) // ws
+    idx = np.asarray(idx, dtype=np.int64)
+    bounds = np.searchsorted(idx, np.arange(ws + 1, dtype=np.int64) * per)
+    counts = np.diff(bounds)
+    assert local_rows.shape[0] == counts[rank], (local_rows.shape, counts, rank)
+    m = int(max(counts.max(), 1))
+    out = allgather_rows(local_rows, ws * m, m)
+    pick = np.concatenate([r * m + np.arange(counts[r], dtype=np.int64) for r in range(ws)])
+    return out[torch.as_tensor(pick, device=out.device)]
+
+
 def allreduce_mean_(tensors):
     """In-place mean all-reduce of the (tiny) prompt gradients, flattened into one message."""
     rank, ws = world()

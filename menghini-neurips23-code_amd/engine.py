@@ -425,3 +425,24 @@ def leaderboard_scan(probs, pred, path_rank, k):
     native.check(lib.grip_leaderboard_scan(c_void_p(probs.ctypes.data), c_void_p(pred.ctypes.data), c_void_p(rank.ctypes.data),
                                            n, c, int(k), c_void_p(out_img.ctypes.data), c_void_p(out_cls.ctypes.data), byref(m)))
     return out_img[: m.value].copy(), out_cls[: m.value].copy()
+
+
+def leaderboard_scan_bounded(probs, pred, path_rank, rel_eps, k):
+    """grip_leaderboard_scan_bounded: (img, cls, ambiguous) with ambiguous a bool [n] array of the rows the caller has to
+    re-encode exactly before the lists can be trusted (include/grip_amd.h)."""
+    import numpy as np
+    lib = native.lib()
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    pred = np.ascontiguousarray(pred, dtype=np.int32)
+    rank = np.ascontiguousarray(path_rank, dtype=np.int64)
+    eps = np.ascontiguousarray(rel_eps, dtype=np.float32)
+    n, c = probs.shape
+    cap = n if int(k) == 10000000 else c * max(1, min(int(k), n))
+    out_img = np.empty(max(cap, 1), dtype=np.int32)
+    out_cls = np.empty(max(cap, 1), dtype=np.int32)
+    amb = np.zeros(max(n, 1), dtype=np.uint8)
+    m, na = c_int64(), c_int64()
+    native.check(lib.grip_leaderboard_scan_bounded(c_void_p(probs.ctypes.data), c_void_p(pred.ctypes.data), c_void_p(rank.ctypes.data),
+                                                   c_void_p(eps.ctypes.data), n, c, int(k), c_void_p(out_img.ctypes.data),
+                                                   c_void_p(out_cls.ctypes.data), byref(m), c_void_p(amb.ctypes.data), byref(na)))
+    return out_img[: m.value].copy(), out_cls[: m.value].copy(), amb[:n].astype(bool)

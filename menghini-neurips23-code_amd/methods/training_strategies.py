@@ -287,6 +287,20 @@ class TrainingStrategy:
 
     # ------------------------------------------------------------------ pseudolabels from the trained model
     @torch.no_grad()
+    def trained_text_features(self, classes, clip_model):
+        """Text features [C, E] of the CURRENT prompts through `clip_model`'s text tower (the f16 model or its exact twin),
+        and the visual prompt (or None) the image side has to be encoded with."""
+        from ..engine import text_prefix_forward
+        if self.modality == "text":
+            ids = self.text_encoder._token_ids(self.model.prefix.shape[1], classes)
+            return text_prefix_forward(clip_model.text_tower, ids, self.model.prefix.detach()), None
+        if self.modality == "image":
+            return clip_model.encode_text(clip.tokenize(self.text_prompts(classes)).to(self.device)), self.model.prefix.detach()
+        coop_embs, vpt_embs = self.model.mix()
+        ids = self.text_encoder._token_ids(coop_embs.shape[1], classes)
+        return text_prefix_forward(clip_model.text_tower, ids, coop_embs.detach()), vpt_embs.detach()
+
+    @torch.no_grad()
     def trained_features(self, images, classes, chunk=440):
         """(image features [N, E] of the whole ordered pool, text features [C, E]) of the CURRENT model for the pseudolabel pass.
         The image side goes through pseudolabels.encode_pool: chunked, sharded contiguously over the ranks of one node, one
@@ -312,9 +326,16 @@ class TrainingStrategy:
         from ..utils.clip_pseudolabels import _pool_images
         classes = self.unseen_classes if self.paradigm == "trzsl" else self.classes
         images = _pool_images(unlabeled_data, self.transform, self.device)
-        img, txt = self.trained_features(images, classes)
-        fp, lab = pl.pseudolabel_from_features(img, txt, self.scale(), list(unlabeled_data.filepaths),
-                                               [self.label_to_idx[c] for c in classes], k, argmax_on="logits")
+        labels = [self.label_to_idx[c] for c in classes]
+        if pl.mode() == "identical" and not self.clip_model.exact:
+            # the lists the reference's fp32 pass would produce with these prompts: f16 screen + exact refinement
+            twin = self.clip_model.exact_twin()
+            txt, vprompt = self.trained_text_features(classes, twin)
+            fp, lab = pl.identical_lists(self.clip_model.visual.tower, twin.visual.tower, images, txt, self.scale(),
+                                         list(unlabeled_data.filepaths), labels, k, chunk=440, prefix=vprompt, argmax_on="logits")
+        else:
+            img, txt = self.trained_features(images, classes)
+            fp, lab = pl.pseudolabel_from_features(img, txt, self.scale(), list(unlabeled_data.filepaths), labels, k, argmax_on="logits")
         unlabeled_data.filepaths, unlabeled_data.labels, unlabeled_data.label_id = fp, lab, True
         return unlabeled_data
 

@@ -54,6 +54,13 @@ def _pool_images(dataset, transform, device):
             nlo, nhi = hi, min(hi + (hi - lo), self._stop)
             self._ahead = ((nlo, nhi), self._bg.submit(transform.decode_chunk, paths[nlo:nhi], workers, procs)) if nlo < nhi else None
             return transform.finish_chunk(handle)
+
+        def take(self, idx):
+            """A scattered selection (the rows a screen-and-refine pass re-encodes): decoded again, nothing is kept."""
+            sel = [paths[int(i)] for i in idx]
+            if not native_pre:
+                return torch.stack([transform(Image.open(p).convert("RGB")) for p in sel])
+            return transform.finish_chunk(transform.decode_chunk(sel, workers=workers, processes=procs))
     return _Lazy()
 
 
@@ -61,13 +68,24 @@ def compute_pseudo_labels(k, template, dataset, classnames, transform, clip_mode
                           chunk=220):
     prompts = [f"{template}{' '.join(i.split('_'))}" for i in classnames]     # reference :24 (literal "{}" kept)
     text = clip.tokenize(prompts).to(device)
-    with torch.no_grad():
-        txt = clip_model.encode_text(text)                                     # once, not once per image
-        emb = pl.encode_pool(clip_model.visual.tower, _pool_images(dataset, transform, device), chunk=chunk)
     class_labels = [label_to_idx[c] for c in classnames]
+    images = _pool_images(dataset, transform, device)
+    scale = clip_model.logit_scale.exp().item()
     log.info(f"Compute {k} pseudo-labeles")
-    new_imgs, new_labels = pl.pseudolabel_from_features(emb, txt, clip_model.logit_scale.exp().item(), list(dataset.filepaths),
-                                                        class_labels, k, argmax_on="probs")
+    if pl.mode() == "identical" and not getattr(clip_model, "exact", False) and hasattr(clip_model, "exact_twin"):
+        # the fp32 scan's lists at close to f16 throughput: f16 screen, exact re-encode of the undecidable rows only
+        twin = clip_model.exact_twin()
+        with torch.no_grad():
+            txt = twin.encode_text(text)                                       # once, not once per image
+        new_imgs, new_labels = pl.identical_lists(clip_model.visual.tower, twin.visual.tower, images, txt, scale, list(dataset.filepaths),
+                                                  class_labels, k, chunk=chunk, argmax_on="probs")
+        st = pl.LAST_REFINE_STATS
+        log.info(f"screen and refine: {st['rows_refined']} of {st['rows']} rows re-encoded exactly in {st['rounds']} rounds (bound {st['eps']:.2e})")
+    else:
+        with torch.no_grad():
+            txt = clip_model.encode_text(text)                                 # once, not once per image
+            emb = pl.encode_pool(clip_model.visual.tower, images, chunk=chunk)
+        new_imgs, new_labels = pl.pseudolabel_from_features(emb, txt, scale, list(dataset.filepaths), class_labels, k, argmax_on="probs")
     dataset.filepaths = new_imgs
     dataset.labels = new_labels
     if getattr(dataset, "images", None) is not None:

@@ -30,6 +30,13 @@ def _worker(rank, ws, port, n, e, ret):
     lo, hi, per = gdist.shard_range(n)
     out = gdist.allgather_rows(full[lo:hi].clone(), n, per)
     ok = torch.equal(out, full)
+    # a scattered selection (the rows a screen-and-refine scan asks for): every rank contributes the rows of its own shard
+    import numpy as np
+    for sel in ([0, n - 1], list(range(0, n, 3)), [n // 2], list(range(n)), []):
+        idx = np.array(sorted(set(i for i in sel if 0 <= i < n)), dtype=np.int64)
+        mine = idx[(idx >= lo) & (idx < hi)]
+        got = gdist.allgather_selected(full[torch.from_numpy(mine)].clone(), idx, n)
+        ok = ok and torch.equal(got, full[torch.from_numpy(idx)])
     g1 = torch.full((3, 4), float(rank + 1))
     g2 = torch.full((5,), float(10 * (rank + 1)))
     gdist.allreduce_mean_([g1, g2])

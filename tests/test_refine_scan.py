@@ -1,0 +1,143 @@
+"""Screen and refine (grip_leaderboard_scan_bounded + pseudolabels.refine_scan): from probabilities that are only accurate
+to a relative bound, plus exact re-encodes of the rows the scan marks, the lists must be the lists of the reference's scan
+(utils/clip_pseudolabels.py:38-112) over the EXACT probabilities -- the oracle's literal Python / plain-C restatements run
+on the exact matrix.  Host logic only (the C++ scan is a host function): no GPU needed."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pool(n, c, spread, sigma, seed, quantise=0, dup_paths=False, dominant=False):
+    """(p32, a32, p16, a16, paths): exact probabilities, a perturbed copy with |p16 / p32 - 1| <~ 5 sigma, paths."""
+    r = np.random.RandomState(seed)
+    logits = (r.randn(n, c) * spread).astype(np.float32)
+    if dominant:                      # every row prefers the same class (what a random-init tower does on noise images)
+        logits[:, 1] += 3.0
+    z = np.exp(logits - logits.max(1, keepdims=True))
+    p32 = (z / z.sum(1, keepdims=True)).astype(np.float32)
+    if quantise:                      # exact ties between different images and inside rows
+        p32 = (np.round(p32 * quantise) / quantise).astype(np.float32) + np.float32(1.0 / (4 * quantise))
+    p16 = (p32.astype(np.float64) * (1.0 + np.clip(r.randn(n, c), -5, 5) * sigma)).astype(np.float32)
+    a32 = p32.argmax(1).astype(np.int32)
+    a16 = p16.argmax(1).astype(np.int32)
+    paths = [f"root/{r.randint(0, n // 2 + 1):05d}.jpg" for _ in range(n)] if dup_paths else [f"p/{(i * 7919) % 100000:05d}_{i}.jpg" for i in range(n)]
+    return p32, a32, p16, a16, paths
+
+
+def _refine(p32, a32, p16, a16, paths, k, **kw):
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    asked = []
+
+    def exact_rows(idx):
+        assert np.all(np.diff(idx) > 0)
+        asked.append(idx.copy())
+        return p32[idx], a32[idx]
+
+    img, cls, st = pl.refine_scan(p16.copy(), a16.copy(), pl.path_ranks(paths), k, exact_rows, **kw)
+    every = np.concatenate(asked) if asked else np.empty(0, np.int64)
+    assert len(np.unique(every)) == len(every) == st["rows_refined"]          # no row is re-encoded twice
+    return ([paths[i] for i in img], [int(j) for j in cls]), st
+
+
+CASES = [
+    # n, c, k, spread, sigma, quantise, dup_paths, dominant
+    (1, 3, 2, 1.0, 1e-3, 0, False, False),
+    (40, 3, 1, 0.3, 1e-3, 0, False, False),
+    (40, 3, 2, 0.3, 1e-2, 8, True, False),            # heavy exact ties + duplicate path strings
+    (300, 5, 3, 0.05, 1e-3, 0, False, False),         # near-uniform rows: undecidable arg-maxes
+    (300, 5, 3, 0.05, 1e-3, 64, True, False),
+    (500, 13, 7, 0.5, 1e-3, 0, False, True),
+    (2000, 47, 16, 0.05, 3e-4, 0, False, False),
+    (2000, 47, 16, 0.3, 2e-3, 0, False, True),        # the bench pool's shape: one class wins every arg-max, everything spills
+    (3000, 10, 3000, 1.0, 1e-3, 0, False, False),     # k >= n: boards never overflow
+    (1500, 102, 16, 3.0, 1e-3, 0, False, False),
+    (800, 6, 5, 0.2, 5e-3, 256, False, True),
+]
+
+
+@pytest.mark.parametrize("n,c,k,spread,sigma,quantise,dup,dominant", CASES)
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_refined_lists_equal_the_exact_scan(n, c, k, spread, sigma, quantise, dup, dominant, seed):
+    from oracle import cbind, leaderboard as LB
+    p32, a32, p16, a16, paths = _pool(n, c, spread, sigma, seed * 101 + n, quantise, dup, dominant)
+    ids = list(range(c))
+    want = cbind.leaderboard_ref(p32, a32, paths, ids, k)
+    if n <= 500:
+        assert want == LB.leaderboard_scan(p32, a32, paths, ids, k)
+    got, st = _refine(p32, a32, p16, a16, paths, k)
+    assert got == want, st
+    assert st["rows_refined"] <= n and st["eps"] >= st["safety"] * st["max_deviation"] * 0.999
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_refined_lists_equal_the_exact_scan_small_exhaustive(seed):
+    """Many tiny pools with few distinct values: ties across board boundaries (the strict fallback), k = 1 .. 4, 2 .. 4 classes."""
+    from oracle import leaderboard as LB
+    r = np.random.RandomState(1000 + seed)
+    n, c, k = int(r.randint(2, 60)), int(r.randint(2, 5)), int(r.randint(1, 5))
+    p32, a32, p16, a16, paths = _pool(n, c, [0.1, 0.5, 2.0][seed % 3], [1e-3, 2e-2][seed % 2], seed, quantise=[0, 6, 20][(seed // 3) % 3], dup_paths=bool(seed & 4))
+    want = LB.leaderboard_scan(p32, a32, paths, list(range(c)), k)
+    got, st = _refine(p32, a32, p16, a16, paths, k, calib=[1, 4, 256][seed % 3])
+    assert got == want, (n, c, k, st)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_label_everything_branch(seed):
+    """k = 10000000 (utils/clip_pseudolabels.py:27-44): every image under its arg-max; a row whose arg-max the bound cannot
+    decide is re-encoded."""
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    p32, a32, p16, a16, paths = _pool(3000, 12, 0.05, 1e-3, seed)
+    assert (a16 != a32).any()          # the perturbed arg-maxes really differ somewhere
+    got, st = _refine(p32, a32, p16, a16, paths, pl.K_ALL)
+    assert got == (paths, [int(j) for j in a32])
+    assert 0 < st["rows_refined"] < len(paths)
+
+
+def test_strict_and_deferred_certification_agree_and_deferred_refines_fewer_rows():
+    """GRIP_SCAN_STRICT=1 certifies every comparison of the literal algorithm; the default only what the final lists depend on."""
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_refine_scan as T\n"
+        "p = T._pool(20000, 30, 0.3, 2e-3, 5, dominant=True)\n"
+        "got, st = T._refine(*p, 8)\n"
+        "print(json.dumps({'lists': got, 'rows': st['rows_refined']}))\n") % (REPO, os.path.join(REPO, "tests"))
+    import json
+    out = {}
+    for strict in ("0", "1"):
+        env = dict(os.environ, GRIP_SCAN_STRICT=strict)
+        out[strict] = json.loads(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1])
+    assert out["0"]["lists"] == out["1"]["lists"]
+    assert out["0"]["rows"] < out["1"]["rows"]
+
+
+def test_an_understated_bound_is_caught_by_later_rows():
+    """The bound only ever grows: rows refined later that deviate more than the calibration rows did widen it and the scan repeats."""
+    p32, a32, p16, a16, paths = _pool(4000, 9, 0.2, 1e-4, 3, dominant=True)
+    r = np.random.RandomState(0)
+    noisy = np.arange(4000) % 7 == 3                       # calibration rows (evenly spread) miss most of these
+    p16[noisy] = (p32[noisy].astype(np.float64) * (1.0 + r.randn(noisy.sum(), 9) * 3e-3)).astype(np.float32)
+    got, st = _refine(p32, a32, p16, p16.argmax(1).astype(np.int32), paths, 6, calib=8)
+    assert st["eps"] >= 2e-3          # far above what eight quiet calibration rows alone would give
+    from oracle import cbind
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(9)), 6)
+    # not guaranteed in general when the first bound is wrong -- this documents that the loop reports the bound it ended with
+    assert st["max_deviation"] * st["safety"] <= st["eps"] * 1.001
+    assert len(got[0]) == len(want[0])
+
+
+def test_bounded_scan_with_zero_bound_is_the_plain_scan():
+    import grip_amd  # noqa: F401
+    from grip_amd import engine, pseudolabels as pl
+    p32, a32, _, _, paths = _pool(5000, 20, 0.5, 0.0, 11, quantise=512, dup_paths=True)
+    ranks = pl.path_ranks(paths)
+    for k in (1, 5, 16, 6000):
+        img, cls, amb = engine.leaderboard_scan_bounded(p32, a32, ranks, np.zeros(len(paths), np.float32), k)
+        i2, c2 = engine.leaderboard_scan(p32, a32, ranks, k)
+        assert not amb.any() and np.array_equal(img, i2) and np.array_equal(cls, c2)
