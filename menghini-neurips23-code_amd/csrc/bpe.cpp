@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -23,6 +25,7 @@ struct grip_bpe {
     int byte_id[256];                                               // byte value -> vocabulary id (without the end-of-word mark)
     std::unordered_map<uint64_t, int32_t, PairHash> rank;           // (id_a << 32 | id_b) -> merge rank
     std::unordered_map<std::string, std::vector<int32_t>> cache;    // pre-token bytes -> ids
+    std::mutex cache_lock;                                          // ctypes releases the GIL during a call: two Python threads may share one handle
     int32_t n_merges = 0, sot = 0, eot = 0;
 };
 
@@ -53,7 +56,8 @@ static void init_byte_ids(grip_bpe* t, std::vector<std::string>& unicode_of) {
 extern "C" int grip_bpe_create(const char* merges, size_t n_bytes, grip_bpe** out) {
     GRIP_REQUIRE(merges && out, "bpe_create: null pointer");
     try {
-        grip_bpe* t = new grip_bpe();
+        std::unique_ptr<grip_bpe> owner(new grip_bpe());     // released into *out only on success: no leak on a bad table or bad_alloc
+        grip_bpe* t = owner.get();
         std::vector<std::string> uni;
         init_byte_ids(t, uni);
         std::unordered_map<std::string, int32_t> vocab;               // symbol string (byte-unicode alphabet) -> id
@@ -68,14 +72,14 @@ extern "C" int grip_bpe_create(const char* merges, size_t n_bytes, grip_bpe** ou
             if (sp == std::string::npos || sp == 0 || sp + 1 >= line.size() || line.find(' ', sp + 1) != std::string::npos) continue;
             const std::string a = line.substr(0, sp), b = line.substr(sp + 1);
             auto ia = vocab.find(a), ib = vocab.find(b);
-            if (ia == vocab.end() || ib == vocab.end()) { delete t; GRIP_REQUIRE(false, "bpe_create: merge %d uses an unknown symbol", t->n_merges); }
+            GRIP_REQUIRE(ia != vocab.end() && ib != vocab.end(), "bpe_create: merge %d uses an unknown symbol", t->n_merges);
             t->rank[((uint64_t)(uint32_t)ia->second << 32) | (uint32_t)ib->second] = t->n_merges;
             vocab[a + b] = 512 + t->n_merges;
             ++t->n_merges;
         }
         t->sot = 512 + t->n_merges;
         t->eot = t->sot + 1;
-        *out = t;
+        *out = owner.release();
         return GRIP_OK;
     } catch (...) { grip_set_error("bpe_create: exception"); return GRIP_ERR_ARG; }
 }
@@ -91,10 +95,14 @@ extern "C" int grip_bpe_special_ids(const grip_bpe* t, int32_t* sot, int32_t* eo
     return GRIP_OK;
 }
 
-static const std::vector<int32_t>& encode_word(grip_bpe* t, const uint8_t* w, int n) {
+// Returns a COPY: the cache may be cleared (or rehashed) by another thread the moment the lock is dropped.
+static std::vector<int32_t> encode_word(grip_bpe* t, const uint8_t* w, int n) {
     const std::string key((const char*)w, (size_t)n);
-    auto hit = t->cache.find(key);
-    if (hit != t->cache.end()) return hit->second;
+    {
+        std::lock_guard<std::mutex> g(t->cache_lock);
+        auto hit = t->cache.find(key);
+        if (hit != t->cache.end()) return hit->second;
+    }
     std::vector<int32_t> sym((size_t)n);
     for (int i = 0; i < n; ++i) sym[(size_t)i] = t->byte_id[w[i]];
     sym[(size_t)n - 1] += 256;                                  // end-of-word form of the last byte
@@ -116,6 +124,7 @@ static const std::vector<int32_t>& encode_word(grip_bpe* t, const uint8_t* w, in
         }
         sym.swap(next);
     }
+    std::lock_guard<std::mutex> g(t->cache_lock);
     if (t->cache.size() > (1u << 20)) t->cache.clear();
     return t->cache.emplace(key, std::move(sym)).first->second;
 }
@@ -124,7 +133,7 @@ static const std::vector<int32_t>& encode_word(grip_bpe* t, const uint8_t* w, in
 extern "C" int grip_bpe_encode_word(grip_bpe* t, const uint8_t* word, int n, int32_t* ids, int cap, int* n_out) {
     GRIP_REQUIRE(t && word && ids && n_out && n > 0, "bpe_encode_word: bad arguments");
     try {
-        const std::vector<int32_t>& v = encode_word(t, word, n);
+        const std::vector<int32_t> v = encode_word(t, word, n);
         GRIP_REQUIRE((int)v.size() <= cap, "bpe_encode_word: output buffer too small");
         memcpy(ids, v.data(), v.size() * sizeof(int32_t));
         *n_out = (int)v.size();

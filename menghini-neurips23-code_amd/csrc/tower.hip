@@ -210,6 +210,7 @@ struct grip_tower {
         const int32_t* eot = nullptr;
         int prefix_classes = 0;
         uint64_t generation = 0;
+        bool consumed = false;     // its backward has run (the backward works in place on the saved activations: one per forward)
     };
     std::map<void*, TrainState> pending;
 };
@@ -459,7 +460,7 @@ static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t
 static void note_forward(grip_tower* t, void* workspace, int train, const Workspace& w, const int32_t* eot, int prefix_classes, uint64_t* generation) {
     if (train) {
         grip_tower::TrainState& st = t->pending[workspace];
-        st.w = w; st.eot = eot; st.prefix_classes = prefix_classes; st.generation = ++t->generation;
+        st.w = w; st.eot = eot; st.prefix_classes = prefix_classes; st.generation = ++t->generation; st.consumed = false;
         if (generation) *generation = st.generation;
     } else {
         t->pending.erase(workspace);
@@ -624,7 +625,7 @@ static int backward_head_of_tower(grip_tower* t, Workspace& w, const float* grad
 
 // Finds the pending train-mode forward of `workspace`.  generation != 0 must equal the number that forward handed out: a later
 // train-mode forward on the same workspace has overwritten the activations, and the gradients would silently be those of
-// the wrong forward.  The entry is consumed: one backward per forward.
+// the wrong forward.  The entry is marked consumed (one backward per forward) and stays until the workspace's next forward.
 static int check_bwd(grip_tower* t, void* workspace, size_t workspace_bytes, uint64_t generation, grip_tower::TrainState& st) {
     GRIP_REQUIRE(t && workspace, "backward: null pointer");
     auto it = t->pending.find(workspace);
@@ -638,9 +639,14 @@ static int check_bwd(grip_tower* t, void* workspace, size_t workspace_bytes, uin
                        (unsigned long long)generation, (unsigned long long)it->second.generation);
         return GRIP_ERR_STATE;
     }
+    if (it->second.consumed) {      // kept until the workspace's next forward so that this is not reported as "no matching forward"
+        grip_set_error("backward: forward #%llu has already been back-propagated (one backward per forward: the backward works in place on the "
+                       "saved activations, so retain_graph / a second backward needs a second forward)", (unsigned long long)it->second.generation);
+        return GRIP_ERR_STATE;
+    }
     if (it->second.w.bytes > workspace_bytes) { grip_set_error("backward: workspace too small"); return GRIP_ERR_WORKSPACE; }
     st = it->second;
-    t->pending.erase(it);
+    it->second.consumed = true;
     return GRIP_OK;
 }
 

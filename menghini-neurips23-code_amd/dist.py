@@ -99,7 +99,9 @@ def native_comm():
     if os.environ.get("GRIP_NATIVE_COMM") != "1" or not is_dist() or _via_host():
         return None
     if _NATIVE is None:
+        import atexit
         _NATIVE = NativeComm()
+        atexit.register(_NATIVE.close)      # ncclCommDestroy before the process group / HIP runtime go away
     return _NATIVE
 
 
@@ -166,12 +168,12 @@ def allreduce_mean_(tensors):
         h = flat.cpu()
         dist.all_reduce(h)
         flat = h.to(flat.device)
+        flat /= ws
     elif native_comm() is not None and flat.is_cuda and flat.dtype == torch.float32:
-        native_comm().allreduce_mean_(flat)
-        flat *= ws          # (the C ABI returns the mean; undo so the common tail below applies)
+        native_comm().allreduce_mean_(flat)          # the C ABI returns the mean
     else:
         dist.all_reduce(flat)
-    flat /= ws
+        flat /= ws
     off = 0
     for t in tensors:
         t.copy_(flat[off: off + t.numel()].view_as(t))

@@ -31,6 +31,32 @@ def require_gpu(device):
     return device
 
 
+_PINNING = []      # stack of lists: workspaces handed out while a HIP graph is being captured (see pin_workspaces)
+
+
+class pin_workspaces:
+    """Context manager around a HIP-graph capture (steps.GraphedStep): every workspace a tower hands out inside it is DEDICATED to
+    that graph -- a train-mode one is never handed to another forward again (a replay would overwrite the activations an eager
+    forward on the same workspace is still holding for its backward), an inference one is a private allocation (the shared
+    inference workspace may be replaced by a larger one and freed under the graph).  The list it yields keeps them alive; the
+    owner un-pins with release_pins when the graph dies."""
+
+    def __enter__(self):
+        self.pins = []
+        _PINNING.append(self.pins)
+        return self.pins
+
+    def __exit__(self, *exc):
+        _PINNING.pop()
+        return False
+
+
+def release_pins(pins):
+    for tower, ws in pins:
+        tower._pinned.pop(ws.data_ptr(), None)
+    pins.clear()
+
+
 class Tower:
     """One frozen CLIP tower (vision or text) living in two HBM blobs behind a native handle."""
 
@@ -56,6 +82,7 @@ class Tower:
         self.handle = h
         self._ws = {}
         self._owners = {}
+        self._pinned = {}        # data_ptr -> workspace dedicated to a captured HIP graph
         self._finalized = False
 
     def __del__(self):
@@ -93,13 +120,21 @@ class Tower:
         key = (batch, n_prefix, bool(train), seq_len)
         if train:
             pool = self._ws.setdefault(key, [])
-            for ws in pool:
-                if not self._busy(ws):
-                    return ws
+            ws = next((w for w in pool if not self._busy(w)), None)
+            if ws is None:
+                nbytes = c_size_t()
+                native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, seq_len, 1, byref(nbytes)))
+                ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
+                pool.append(ws)
+            if _PINNING:
+                self._pinned[ws.data_ptr()] = ws
+                _PINNING[-1].append((self, ws))
+            return ws
+        if _PINNING:      # inside a graph capture: a private inference workspace (kept alive by the graph's owner)
             nbytes = c_size_t()
-            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, seq_len, 1, byref(nbytes)))
+            native.check(self.lib.grip_workspace_bytes(self.handle, batch, n_prefix, seq_len, 0, byref(nbytes)))
             ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=self.device)
-            pool.append(ws)
+            _PINNING[-1].append((self, ws))
             return ws
         ws = self._ws.get(key)
         if ws is None:
@@ -114,6 +149,8 @@ class Tower:
         return ws
 
     def _busy(self, ws):
+        if ws.data_ptr() in self._pinned:
+            return True
         owner = self._owners.get(ws.data_ptr())
         return owner is not None and owner() is not None
 

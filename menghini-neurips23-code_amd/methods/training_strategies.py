@@ -92,6 +92,7 @@ class TrainingStrategy:
         self.optimizer = torch.optim.SGD(params, lr=float(c.LR), weight_decay=float(c.DECAY), momentum=float(getattr(c, "MOMENTUM", 0.0)))
         self.scheduler = make_scheduler(self.optimizer, c)
         self.loss_func = torch.nn.CrossEntropyLoss()
+        self._model_gen = getattr(self, "_model_gen", 0) + 1       # a new model / optimizer: captured step graphs of the old one are stale
 
     def unwrap_model(self):
         return self.model
@@ -218,9 +219,60 @@ class TrainingStrategy:
         lut[idx] = torch.arange(len(classes), device=self.device)
         return classes, idx, lut
 
+    def _graphed_step(self, classes):
+        """The HIP-graph replay of this strategy's prompt step (steps.Graphed*Step) for the current model and class list; rebuilt
+        whenever define_model made a new model / optimizer."""
+        key = (self._model_gen, tuple(classes))
+        if getattr(self, "_gkey", None) != key:
+            if self.modality == "text":
+                self.model.classes = classes
+                g = steps.GraphedCoopFeatureStep(self.model, self.clip_model, self.optimizer)
+            elif self.modality == "image":
+                g = steps.GraphedVptStep(self.model, self.fixed_text_features(classes), self.scale(), self.optimizer)
+            else:
+                self.model.classes = classes
+                g = steps.GraphedUptStep(self.model, self.scale(), self.optimizer)
+            self._gkey, self._gstep = key, g
+        return self._gstep
+
     def _train_epoch(self, train_loader, only_seen=False):
+        """One epoch of the strategy's prompt step (the `_train_epoch` bodies of the reference, e.g. textual_prompt.py:63-159).
+        Default: every full-sized batch replays the step's forward + backward from a HIP graph (steps.Graphed*Step; a batch of
+        another shape -- the ragged last one -- runs the same kernels eagerly), the textual modality encodes the frozen image
+        tower `IMAGE_LOOKAHEAD` (13) batches at a time when its features are not cached, and loss / accuracy accumulate on the
+        device: one host synchronisation per epoch instead of three per batch.  `GRAPH_STEPS: False` or gradient accumulation
+        (ACCUMULATION_ITER > 1) take the eager per-batch path."""
         classes, ids, lut = self._class_space(only_seen)
         accum = int(getattr(self.config, "ACCUMULATION_ITER", 1))
+        if accum != 1 or not getattr(self.config, "GRAPH_STEPS", True):
+            return self._train_epoch_eager(train_loader, classes, ids, lut, accum)
+        g = self._graphed_step(classes)
+        total = torch.zeros((), dtype=torch.float64, device=self.device)      # the sum the eager loop forms in Python doubles
+        correct = torch.zeros((), dtype=torch.int64, device=self.device)
+        count = 0
+
+        def batches():
+            for img, _, _, label, names in train_loader:
+                w = self.row_weights(label.tolist(), names)          # labels are still on the host here: no synchronisation
+                yield img.to(self.device, non_blocking=True), label.to(self.device, non_blocking=True), w.to(self.device, non_blocking=True), list(names)
+
+        if self.modality == "text":
+            if getattr(self.config, "CACHE_FROZEN_FEATURES", True):
+                stream = ((self.frozen_image_features(img, names), label, w) for img, label, w, names in batches())
+            else:           # every image is encoded every time it is used, a group of batches per frozen-tower forward
+                stream = steps.lookahead_image_features(self.clip_model, ((img, label, w) for img, label, w, _ in batches()),
+                                                        int(getattr(self.config, "IMAGE_LOOKAHEAD", 13)))
+        else:
+            stream = ((img, label, w) for img, label, w, _ in batches())
+        for x, label, w in stream:
+            total += g(x, lut[label], w)
+            correct += (ids[g.logits.argmax(1)] == label).sum()
+            count += len(label)
+        self.update_scheduler()
+        n_batches = max(len(train_loader), 1)
+        return float(total) / n_batches, int(correct) / max(count, 1)
+
+    def _train_epoch_eager(self, train_loader, classes, ids, lut, accum):
         total, correct, count = 0.0, 0, 0
         for i, (img, _, _, label, names) in enumerate(train_loader):
             img, label = img.to(self.device), label.to(self.device)

@@ -8,6 +8,7 @@ The per-sample `.item()` host syncs of the reference loops are gone: labels stay
 import torch
 
 from . import dist as gdist
+from . import engine
 from .engine import CosineHeadFn, WeightedCEFn
 
 
@@ -38,15 +39,15 @@ def _side_stream(device):
     return _SIDE[key]
 
 
-def _finish(loss, params, optimizer):
+def _finish(loss, params, optimizer, logits=None):
     loss.backward()
     gdist.allreduce_mean_([p.grad for p in params if p.grad is not None])
     optimizer.step()
     optimizer.zero_grad(set_to_none=False)
-    return loss.detach()
+    return loss.detach() if logits is None else (loss.detach(), logits.detach())
 
 
-def coop_step(model, clip_model, images, labels, row_weight, optimizer, image_features=None):
+def coop_step(model, clip_model, images, labels, row_weight, optimizer, image_features=None, return_logits=False):
     """Textual prompt step: text tower forward+backward over all class prompts, frozen image tower
     forward only (or cached features)."""
     side = None
@@ -63,23 +64,23 @@ def coop_step(model, clip_model, images, labels, row_weight, optimizer, image_fe
         image_features.record_stream(torch.cuda.current_stream())
     logits = CosineHeadFn.apply(image_features, text_features, clip_model.logit_scale.exp().item())
     loss = WeightedCEFn.apply(logits, labels, row_weight)
-    return _finish(loss, [model.prefix], optimizer)
+    return _finish(loss, [model.prefix], optimizer, logits if return_logits else None)
 
 
-def vpt_step(model, text_features, logit_scale, images, labels, row_weight, optimizer):
+def vpt_step(model, text_features, logit_scale, images, labels, row_weight, optimizer, return_logits=False):
     """Visual prompt step: image tower forward+backward; text features fixed for the epoch."""
     image_features = model(images)
     logits = CosineHeadFn.apply(image_features, text_features, logit_scale)
     loss = WeightedCEFn.apply(logits, labels, row_weight)
-    return _finish(loss, [model.prefix], optimizer)
+    return _finish(loss, [model.prefix], optimizer, logits if return_logits else None)
 
 
-def upt_step(model, logit_scale, images, labels, row_weight, optimizer):
+def upt_step(model, logit_scale, images, labels, row_weight, optimizer, return_logits=False):
     """Multimodal prompt step: mixer + both towers forward and backward."""
     text_features, image_features = model(images, model.classes)
     logits = CosineHeadFn.apply(image_features, text_features, logit_scale)
     loss = WeightedCEFn.apply(logits, labels, row_weight)
-    return _finish(loss, [p for p in model.parameters() if p.requires_grad], optimizer)
+    return _finish(loss, [p for p in model.parameters() if p.requires_grad], optimizer, logits if return_logits else None)
 
 
 class GraphedStep:
@@ -97,6 +98,13 @@ class GraphedStep:
         self.optimizer = optimizer
         self.graph = None
         self.key = None
+        self._pins = []
+
+    def __del__(self):
+        try:
+            engine.release_pins(self._pins)
+        except Exception:
+            pass
 
     # -- subclass interface
     def params(self):
@@ -113,7 +121,9 @@ class GraphedStep:
 
     # -- machinery
     def _body(self):
-        loss = WeightedCEFn.apply(self.forward_logits(), self.y, self.w)
+        logits = self.forward_logits()
+        self.logits = logits.detach()      # [B, C] of the step just run (a static buffer of the graph; the eager fallback's own tensor)
+        loss = WeightedCEFn.apply(logits, self.y, self.w)
         loss.backward()
         return loss.detach()
 
@@ -134,10 +144,12 @@ class GraphedStep:
         for p in ps:
             p.grad = torch.zeros_like(p)           # the captured backward accumulates into these buffers
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # the workspaces the captured forwards take are dedicated to this graph (never handed to an eager forward while it lives)
+        with engine.pin_workspaces() as self._pins, torch.cuda.graph(self.graph):
             for p in ps:
                 p.grad.zero_()
             self.loss = self._body()
+        self._graph_logits = self.logits           # the graph's static output buffer
         self.grads = [p.grad for p in ps]
 
     def __call__(self, images, labels, row_weight):
@@ -146,13 +158,15 @@ class GraphedStep:
         if self.shape_key(images) != self.key:
             for p in self.params():
                 p.grad = None                      # (the graph's gradient buffers hold the previous replay's values)
-            return self.eager(images, labels, row_weight)
+            loss, self.logits = self.eager(images, labels, row_weight)
+            return loss
         self.x.copy_(images)
         self.y.copy_(labels)
         self.w.copy_(row_weight)
         for p, g in zip(self.params(), self.grads):
             p.grad = g
         self.graph.replay()
+        self.logits = self._graph_logits
         gdist.allreduce_mean_(self.grads)
         self.optimizer.step()
         return self.loss
@@ -182,7 +196,7 @@ class GraphedCoopStep(GraphedStep):
         return CosineHeadFn.apply(image_features, text_features, self.scale)
 
     def eager(self, images, labels, row_weight):
-        return coop_step(self.model, self.clip_model, images, labels, row_weight, self.optimizer)
+        return coop_step(self.model, self.clip_model, images, labels, row_weight, self.optimizer, return_logits=True)
 
 
 class GraphedCoopFeatureStep(GraphedStep):
@@ -204,7 +218,7 @@ class GraphedCoopFeatureStep(GraphedStep):
         return CosineHeadFn.apply(self.x, self.model(self.model.classes), self.scale)
 
     def eager(self, feats, labels, row_weight):
-        return coop_step(self.model, self.clip_model, None, labels, row_weight, self.optimizer, image_features=feats)
+        return coop_step(self.model, self.clip_model, None, labels, row_weight, self.optimizer, image_features=feats, return_logits=True)
 
 
 def lookahead_image_features(clip_model, batches, group=8):
@@ -250,7 +264,7 @@ class GraphedVptStep(GraphedStep):
         return CosineHeadFn.apply(self.model(self.x), self.text_features, self.scale)
 
     def eager(self, images, labels, row_weight):
-        return vpt_step(self.model, self.text_features, self.scale, images, labels, row_weight, self.optimizer)
+        return vpt_step(self.model, self.text_features, self.scale, images, labels, row_weight, self.optimizer, return_logits=True)
 
 
 class GraphedUptStep(GraphedStep):
@@ -271,4 +285,4 @@ class GraphedUptStep(GraphedStep):
         return CosineHeadFn.apply(image_features, text_features, self.scale)
 
     def eager(self, images, labels, row_weight):
-        return upt_step(self.model, self.scale, images, labels, row_weight, self.optimizer)
+        return upt_step(self.model, self.scale, images, labels, row_weight, self.optimizer, return_logits=True)

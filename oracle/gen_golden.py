@@ -259,10 +259,10 @@ def fpl_losses(out):
 
 
 def main():
-    """python oracle/gen_golden.py [small] [vitb16] [vitl14] [leaderboard]   (no argument = all four groups)"""
+    """python oracle/gen_golden.py [small] [vitb16] [vitb32] [vitl14] [leaderboard]   (no argument = all groups)"""
     os.makedirs(OUT, exist_ok=True)
     cbind.build()
-    groups = set(sys.argv[1:]) or {"small", "vitb16", "vitl14", "leaderboard"}
+    groups = set(sys.argv[1:]) or {"small", "vitb16", "vitb32", "vitl14", "leaderboard"}
     classes = ["forest", "annual crop land", "river", "sea lake", "highway"]
 
     if "small" in groups:
@@ -280,6 +280,13 @@ def main():
         towers("ViT-B/16", 2, classes[:3], 16, "g3", big, with_grad=True)
         upt("ViT-B/16", 2, classes[:3], 4, "g4b", big)
         np.savez_compressed(os.path.join(OUT, "golden_vitb16.npz"), **big)
+
+    if "vitb32" in groups:
+        # ViT-B/32: the encoder every shipped script of the reference defaults to (scripts/run_pseudolabels_ssl.sh:4): patch 32
+        # (im2col K = 3 072), S = 50 / 66; 2 images, 3 prompts, 16 prompt tokens, forward of both towers + both prompt gradients
+        b32 = {}
+        towers("ViT-B/32", 2, classes[:3], 16, "g6", b32, with_grad=True)
+        np.savez_compressed(os.path.join(OUT, "golden_vitb32.npz"), **b32)
 
     if "vitl14" in groups:
         # BASELINE.json configs[4]: ViT-L/14@336px (d = 1024, 24 layers, 16 heads, S = 577 / 593, E = 768) + the 12-head 768-wide

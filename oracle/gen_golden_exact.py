@@ -2,6 +2,7 @@
 container (imports the reference from /root/reference, unmodified):
 
     python oracle/gen_golden_exact.py        # ~7 min on 8 cores; writes tests/golden/exact_vitb16_c{10,102}.npz
+    python oracle/gen_golden_exact.py 10000  # ~40 min; writes tests/golden/exact_vitb16_c102_n10000.npz (102 classes only)
 
 The reference's own utils/clip_pseudolabels.compute_pseudo_labels (:13-117) is driven over N = 2 000 seeded structured
 images (grip_amd.data.synthetic, regenerated from the seed on the GPU box) on the CPU fp32 oracle CLIP (ViT-B/16
@@ -34,7 +35,8 @@ from grip_amd.data.synthetic import pool_paths, structured_images  # noqa: E402
 from utils import clip_pseudolabels as RP  # noqa: E402  (REFERENCE, unmodified)
 from oracle import leaderboard as LB  # noqa: E402
 
-N, C, SEED, NAME = 2000, 102, 4242, "ViT-B/16"
+N, C, SEED, NAME = (int(sys.argv[1]) if len(sys.argv) > 1 else 2000), 102, 4242, "ViT-B/16"
+BIG = N != 2000      # the larger pool: 102 classes only, own file name
 
 
 class _FakeImg:
@@ -97,7 +99,8 @@ def main():
     RP.Image.open = lambda path: _FakeImg(index[path])
     RP.tqdm = lambda it: it
     t0 = time.time()
-    for tag, classnames in (("c10", EUROSAT), ("c102", [f"kind_{i:03d}" for i in range(C)])):
+    sets = (("c10", EUROSAT), ("c102", [f"kind_{i:03d}" for i in range(C)])) if not BIG else ((f"c102_n{N}", [f"kind_{i:03d}" for i in range(C)]),)
+    for tag, classnames in sets:
         label_to_idx = {c: i for i, c in enumerate(classnames)}
         out = {"seed": np.int64(SEED)}
         with torch.no_grad():

@@ -25,6 +25,12 @@ def golden_vitb16():
 
 
 @pytest.fixture(scope="session")
+def golden_vitb32():
+    import numpy as np
+    return np.load(os.path.join(REPO, "tests", "golden", "golden_vitb32.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_vitl14():
     import numpy as np
     return np.load(os.path.join(REPO, "tests", "golden", "golden_vitl14_336.npz"))

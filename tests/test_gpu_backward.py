@@ -89,6 +89,32 @@ def test_cosine_head_and_ce_backward():
     assert_grad_close(gt, txt.grad.cpu(), "d txt", cos_tol=1e-5, rel_tol=1e-3)
 
 
+def test_weighted_ce_kernel_reproduces_the_three_reference_fpl_losses(golden_small):
+    """grip_weighted_ce on the reference-generated G7 block: g7.{ssl, trzsl, ul} are the FPL losses the reference's own
+    define_loss_function bodies returned on g7.logits (semi_supervised_learning/textual_fpl.py:123-165, transductive_zsl/
+    textual_fpl.py:117-147, unsupervised_learning/visual_fpl.py:107-122; oracle/gen_golden.py); the kernel with the three
+    fpl_row_weights variants must return them, and its gradient must be the autograd gradient of the same expression."""
+    import numpy as np
+
+    import grip_amd  # noqa: F401
+    from grip_amd.engine import WeightedCEFn
+    from grip_amd.steps import fpl_row_weights
+    g = golden_small
+    labels = torch.tensor([0, 3, 1, 4, 2, 3])
+    unl = [True, False, True, True, False, True]
+    variants = {"ssl": fpl_row_weights(unl, gamma_seen=4 / 2, gamma_pseudo=1.0),
+                "trzsl": fpl_row_weights([int(l) in (3, 4) for l in labels], gamma_seen=1.0, gamma_pseudo=3 / 3),
+                "ul": fpl_row_weights([False] * 6)}
+    for name, w in variants.items():
+        logits = torch.from_numpy(g["g7.logits"]).cuda().requires_grad_(True)
+        loss = WeightedCEFn.apply(logits, labels.cuda(), w.cuda())
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), float(g[f"g7.{name}"]), rtol=2e-6, err_msg=name)
+        ref_in = torch.from_numpy(g["g7.logits"]).requires_grad_(True)
+        (torch.nn.functional.cross_entropy(ref_in, labels, reduction="none") * w).sum().backward()
+        torch.testing.assert_close(logits.grad.cpu(), ref_in.grad, rtol=1e-5, atol=1e-7)
+
+
 @pytest.fixture(scope="module")
 def models():
     import grip_amd  # noqa: F401
@@ -269,6 +295,19 @@ def test_golden_vitb16_prompt_gradients(models, golden_vitb16):
     model = ImagePrefixModel(_inputs("g3.vprefix", (16, 768), 0.02).cuda(), CustomImageEncoder(m.visual), device="cuda")
     (model(x) ** 2).sum().backward()
     assert_grad_close(model.prefix.grad, g["g3.vision_p16_grad_prefix"], "g3 visual prompt grad")
+
+
+def test_golden_vitb32_prompt_gradients(models, golden_vitb32):
+    """ViT-B/32 (the reference scripts' default encoder): CoOp gradient through its text tower and the VPT gradient through the
+    12-layer ViT at S = 66, against autograd through the reference's own wrappers."""
+    import grip_amd  # noqa: F401
+    from grip_amd.models import CustomImageEncoder, ImagePrefixModel
+    m, g = models("ViT-B/32"), golden_vitb32
+    _full_size_text_gradient(m, g, "g6", 512)
+    x = _inputs("g6.x", (2, 3, 224, 224)).cuda()
+    model = ImagePrefixModel(_inputs("g6.vprefix", (16, 768), 0.02).cuda(), CustomImageEncoder(m.visual), device="cuda")
+    (model(x) ** 2).sum().backward()
+    assert_grad_close(model.prefix.grad, g["g6.vision_p16_grad_prefix"], "g6 visual prompt grad")
 
 
 def test_golden_vitb16_upt_end_to_end(models, golden_vitb16):

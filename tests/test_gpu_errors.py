@@ -81,8 +81,16 @@ def test_two_forwards_before_backward(model):
     with pytest.raises(native.GripError, match="overwritten"):
         t.vit_backward(torch.ones(2, 128, device="cuda"), pd, ws, gen_a)
     t.vit_backward(torch.ones(2, 128, device="cuda"), pd, ws, ws.generation)     # the live one still works ...
-    with pytest.raises(native.GripError, match="train-mode forward"):
-        t.vit_backward(torch.ones(2, 128, device="cuda"), pd, ws, ws.generation)  # ... exactly once
+    with pytest.raises(native.GripError, match="already been back-propagated"):
+        t.vit_backward(torch.ones(2, 128, device="cuda"), pd, ws, ws.generation)  # ... exactly once, and the second one says why
+    # a workspace a captured HIP graph replays into is never handed to an eager forward (its activations would be overwritten)
+    from grip_amd import engine
+    with engine.pin_workspaces() as pins:
+        _, ws_g = t.vit_forward(x1, pd, train=True)
+    _, ws_e = t.vit_forward(x1, pd, train=True)
+    assert ws_e is not ws_g and t._busy(ws_g)
+    engine.release_pins(pins)
+    assert not t._busy(ws_g)
 
 
 def test_bad_arguments_are_rejected(model):

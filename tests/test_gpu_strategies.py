@@ -231,3 +231,32 @@ def test_graphed_vpt_and_upt_steps_equal_eager():
     e, gr = res[False], res[True]
     assert e[0] == gr[0] and torch.equal(e[1], gr[1])
     assert e[2] == gr[2] and torch.equal(e[3], gr[3]) and torch.equal(e[4], gr[4])
+
+
+@pytest.mark.parametrize("cls_name,paradigm", [("TextualPrompt", "ssl"), ("VisualPrompt", "ul"), ("MultimodalPrompt", "trzsl"), ("TextualFPL", "trzsl")])
+def test_train_epoch_graph_replay_equals_eager_epoch(tmp_path, monkeypatch, cls_name, paradigm):
+    """TrainingStrategy._train_epoch (what run_main_* executes) replays the prompt step from a HIP graph, accumulates loss and
+    accuracy on the device and encodes the frozen tower several batches ahead; with GRAPH_STEPS False it runs the eager per-batch
+    loop.  Same losses, accuracies and trained parameters, bit for bit -- including a ragged last batch (eager fallback inside the
+    graphed step) and un-cached frozen features (look-ahead encode)."""
+    import grip_amd  # noqa: F401
+    from grip_amd import methods
+    from grip_amd.data import TensorPoolDataset
+    from grip_amd.methods.main import synthetic_pool
+    monkeypatch.chdir(tmp_path)
+    classes, files, images, names = synthetic_pool(5, 7, 64, 5)          # 35 images: batches of 8 + a ragged 3
+    l2i = {c: i for i, c in enumerate(classes)}
+    out = []
+    for graph in (True, False):
+        conf = _conf(MODEL="x", LEARNING_PARADIGM=paradigm, BATCH_SIZE=8, GRAPH_STEPS=graph, CACHE_FROZEN_FEATURES=False, IMAGE_LOOKAHEAD=3,
+                     TEXT_PREFIX_SIZE=4, VISION_PREFIX_SIZE=4)
+        data = TensorPoolDataset(files, images.cuda(), labels=names, label_map=l2i)
+        m = getattr(methods, cls_name)(conf, l2i, classes, classes[:3], classes[3:], "cuda") if not cls_name.endswith("FPL") else \
+            getattr(methods, cls_name)(conf, l2i, "", classes, classes[:3], classes[3:], "cuda")
+        m.define_model(classes)
+        loader = m._loader(data, True)
+        stats = [m._train_epoch(loader) for _ in range(3)]
+        out.append((stats, [p.detach().clone() for p in m.model.parameters() if p.requires_grad]))
+    (s_g, p_g), (s_e, p_e) = out
+    assert s_g == s_e, (s_g, s_e)
+    assert all(torch.equal(a, b) for a, b in zip(p_g, p_e))
