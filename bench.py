@@ -243,17 +243,31 @@ def dominant(launches, ms, fl):
     return dom, tf
 
 
-def pmc_entry(kernel):
-    """Per-launch HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) and MFMA utilisation of `kernel` from the separate rocprofv3 --pmc
-    passes of this same command that are committed under profiles/ (PMC counters cannot be collected inside a timed run):
-    (bytes_per_launch, mfma_util) or (None, None)."""
+def full_kernel_name(slot):
+    """The instantiation rocprofv3 names for a profiler slot, template arguments included (csrc/gemm.hip launch_k64p: the persistent
+    GEMM carries its epilogue form and the single-block flag): `gemm_k64p_kernel<9, 1, true>`.  None when this host cannot tell."""
+    v, e = divmod(slot, 16)
+    if v != 6:
+        return kname(slot).split(" [")[0]
+    env = int(os.environ.get("GRIP_GEMM_EMODE", "421"))
+    mode = env if env < 100 else (env // 100 if e == 7 else (env // 10) % 10 if e == 8 else env % 10)
+    if e == 9 and mode in (2, 4):
+        mode = 1
+    if e not in (7, 8, 9):
+        return None
+    sd = os.environ.get("GRIP_GEMM_SD", "1") != "0"
+    return f"gemm_k64p_kernel<{e}, {mode}, true>" if sd else f"gemm_k64p_kernel<{e}, {mode}>"
+
+
+def pmc_entry(slot):
+    """Per-launch HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) and MFMA utilisation of the dominant kernel from the separate rocprofv3 --pmc
+    passes of this same command that are committed under profiles/ (PMC counters cannot be collected inside a timed run).  The entry
+    is used only when the file describes EXACTLY the instantiation that ran (name and every template argument); otherwise
+    (None, None): a traffic figure of another kernel is worse than none."""
     try:
         with open(os.path.join(REPO, TRAFFIC_FILE)) as f:
             kernels = json.load(f)["kernels"]
-        name = kernel.split(" [")[0]
-        if name not in kernels:         # the persistent GEMM carries its epilogue form as a second template argument: <9> -> <9, 1>
-            name = next(k for k in kernels if k.startswith(name[:-1] + ","))
-        t = kernels[name]
+        t = kernels[full_kernel_name(slot)]
         return t.get("bytes_per_launch"), t.get("mfma_util")
     except Exception:
         return None, None
@@ -537,7 +551,7 @@ def main():
     f_img_x = F_IMG if os.environ.get("GRIP_LAST_BLOCK_FULL", "0") not in ("", "0") else vit_flops_executed()
     executed = images * f_img_x + args.steps * args.classes * text_flops(seq_zs) * ws \
         + args.steps * loop.train_steps * ws * (args.batch * f_img_x + 2 * args.classes * text_flops(seq))
-    traffic, mfma_util = pmc_entry(kname(dom))
+    traffic, mfma_util = pmc_entry(dom)
     peak = PEAK_F32_TFLOPS if dom < 16 else PEAK_F16_TFLOPS       # profiler variant 0 = the exact tower's f32 GEMM
     rs = loop.refine_stats
     if rs is not None:      # the rows the identical pass re-encoded with the f32 tower are work the engine issued on top of the algorithmic count
@@ -586,11 +600,11 @@ def main():
                       f"row of its output is read) and the text tower's {seq_zs} (zero-shot) / {seq} (CoOp) encoded positions (positions after the last "
                       "EOT cannot influence any output); results are identical either way",
         "roofline": {
-            "bound": "mfma", "kernel": kname(dom),
+            "bound": "mfma", "kernel": kname(dom), "kernel_instantiation": full_kernel_name(dom),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "mfma_util_pmc": mfma_util,
             "traffic_source": f"{TRAFFIC_FILE}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES), "
-                              "read from the committed file, not measured in this run",
+                              "read from the committed file, not measured in this run; null when the file does not describe exactly `kernel_instantiation`",
             "launches_timed": int(launches[dom]), "avg_launch_ms": ms[dom] / max(launches[dom], 1),
             "all_gemm": {kname(i): {"launches": int(launches[i]), "ms": round(float(ms[i]), 3),
                                         "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1) if ms[i] > 0 else None}
