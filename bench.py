@@ -47,6 +47,25 @@ PEAK_F32_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_16x16x4_f32), the exa
 EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE", "EPI_LNFOLD_F16",
              "EPI_LNFOLD_GELU_F16", "EPI_BIAS_RESID_STATS"]
 TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+PEAK_CLOCK_MHZ = 2400.0  # the shader clock behind the 2.5 PFLOP/s figure
+
+
+def clock_marker(label):
+    """`##clock_trace <label>` on stderr for tools/clock_trace.py (GRIP_CLOCK_MARKERS=1)."""
+    if os.environ.get("GRIP_CLOCK_MARKERS") == "1":
+        print(f"##clock_trace {label}", file=sys.stderr, flush=True)
+
+
+def clock_sampler():
+    """The hwmon sampler of tools/clock_trace.py (shader clock / package power at 20 Hz from a background thread), or None when
+    the box exposes no readable amdgpu hwmon files."""
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from clock_trace import ClockSampler
+        s = ClockSampler(20.0)
+        return s if s.available() else None
+    except Exception:
+        return None
 
 
 def text_flops(seq, width=512, layers=12):
@@ -104,37 +123,56 @@ class Loop:
         self.graphed_f = steps.GraphedCoopFeatureStep(self.model, self.m, self.opt) if args.graph else None
         self.twin = self.m.exact_twin() if args.mode == "identical" else None
         self.refine_stats = None
+        self.stage = {k: 0.0 for k in ("encode_f16", "allgather", "head_scan", "refine_exact", "train")}     # wall seconds per stage, this rank
         self.t_pl = self.t_tr = 0.0
         self.m_selected = 0
         self.train_steps = 0
         self.last_lists = None
+
+    def tick(self):
+        """Stage boundary: the device work of the stage is done when the clock is read (the next stage depends on it anyway)."""
+        torch.cuda.synchronize()
+        return time.perf_counter()
 
     def identical_pass(self, streams):
         """(i)-(iii) with the index guarantee (pseudolabels.identical_lists on this rank's resident shard): f16 encode of the
         whole pool, head against the EXACT text features, error-bounded scan, exact re-encode of the rows it marks, until the
         scan certifies that its lists are the fp32 scan's."""
         a = self.args
+        st = self.stage
         with torch.no_grad():
+            t0 = self.tick()
             txt = self.twin.encode_text(self.zs_tokens)
             local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
             self.m.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk, streams=streams)
+            t1 = self.tick()
             emb = gdist.allgather_rows(local, self.n_total, a.pool)
+            t2 = self.tick()
             scale = self.m.logit_scale.exp().item()
             _, probs, _, am_p = engine.cosine_head(emb, txt, scale)
             probs_h, pred_h = probs.cpu().numpy(), am_p.cpu().numpy()
             lo = self.rank * a.pool
             tower32 = self.twin.visual.tower
+            t_exact = [0.0]
 
             def exact_rows(idx):
+                ta = time.perf_counter()
                 mine = torch.from_numpy(idx[(idx >= lo) & (idx < lo + a.pool)] - lo).to(self.device)
                 rows = torch.empty(len(mine), self.d.embed_dim, dtype=torch.float32, device=self.device)
                 if len(mine):
                     tower32.encode_chunks(lambda s, e: self.pool[mine[s:e]], rows, 0, len(mine), a.exact_chunk, streams=1)
                 rows = gdist.allgather_selected(rows, idx, self.n_total)
                 _, p, _, ap = engine.cosine_head(rows, txt, scale)
-                return p.cpu().numpy(), ap.cpu().numpy()
+                out = p.cpu().numpy(), ap.cpu().numpy()
+                t_exact[0] += time.perf_counter() - ta
+                return out
 
             img, cls, self.refine_stats = pl.refine_scan(probs_h, pred_h, self.ranks, self.k, exact_rows)
+            t3 = self.tick()
+        st["encode_f16"] += t1 - t0
+        st["allgather"] += t2 - t1
+        st["refine_exact"] += t_exact[0]
+        st["head_scan"] += t3 - t2 - t_exact[0]
         return img, cls
 
     def pseudolabel_pass(self, model, streams):
@@ -151,13 +189,19 @@ class Loop:
                 marks.append((name, time.perf_counter()))
 
         with torch.no_grad():
+            t0 = self.tick()
             txt = model.encode_text(self.zs_tokens)
             mark("text")
             # every rank encodes its own pool; embeddings are gathered in global (rank-major) order
             local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
             model.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk if model is self.m else a.exact_chunk, streams=streams)
             mark("encode")
+            t1 = self.tick()
             emb = gdist.allgather_rows(local, self.n_total, a.pool)
+            t2 = self.tick()
+            if model is self.m:
+                self.stage["encode_f16"] += t1 - t0
+                self.stage["allgather"] += t2 - t1
             logits, probs, am_l, am_p = engine.cosine_head(emb, txt, model.logit_scale.exp().item())
             mark("gather+head")
             probs_h = probs.cpu().numpy()
@@ -213,6 +257,7 @@ class Loop:
         t2 = time.perf_counter()
         self.t_pl += t1 - t0
         self.t_tr += t2 - t1
+        self.stage["train"] += t2 - t1
         self.m_selected = len(img)
         self.train_steps = n_steps
         self.last_lists = (img, cls)
@@ -475,6 +520,8 @@ def main():
     ap.add_argument("--mode", default="identical", choices=("identical", "f16"),
                     help="identical (default, what utils.pseudolabel_top_k does): the pass returns the fp32 scan's lists -- f16 encode of the pool, "
                          "error-bounded scan, exact (f32) re-encode of the rows it marks; f16: the f16 towers' own lists (boundary items may differ)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --pool is the TOTAL number of images, split evenly over the ranks (default: weak, --pool images per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the fp32 comparison-mode block")
     ap.add_argument("--exact-chunk", type=int, default=220)
@@ -490,35 +537,61 @@ def main():
     rank, ws = gdist.init_from_env()
     if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
+    total_images = args.pool
+    if args.strong:
+        args.pool = (args.pool + ws - 1) // ws
     local_rank = gdist.local_device_index()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    numa = gdist.pin_to_gpu_numa_node(local_rank)        # host threads (scan, launches) next to this rank's GPU
     lib = native.lib()
     on_host = ws > 1 and torch.distributed.get_backend() == "gloo"
-    seen = [{"rank": rank, "device": local_rank}]
+    seen = [{"rank": rank, "device": local_rank, "numa_node": numa}]
     if ws > 1:
         gathered = [None] * ws
         torch.distributed.all_gather_object(gathered, seen[0])
         seen = gathered
 
     loop = Loop(args, device, rank, ws)
+    clock_marker("warmup")
     for _ in range(args.warmup):
         loop.step()
     loop.t_pl = loop.t_tr = 0.0
+    for k in loop.stage:
+        loop.stage[k] = 0.0
     lib.grip_profile_enable(1)
+    sampler = clock_sampler() if rank == 0 else None
     gdist.barrier()
     torch.cuda.synchronize()
+    clock_marker("timed")
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loop.step()
     gdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    clocks = sampler.stop() if sampler is not None else None
+    clock_marker("after_timed")
     el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else device)
     if ws > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = el.item()
     launches, ms, fl = profile_collect(lib)
+    # wall seconds per stage of the timed loop on every rank: where a scaling curve bends is read off these
+    stage_names = list(loop.stage)
+    mine = torch.tensor([loop.stage[k] for k in stage_names], dtype=torch.float64, device="cpu" if on_host else device)
+    allst = [torch.zeros_like(mine) for _ in range(ws)]
+    if ws > 1:
+        torch.distributed.all_gather(allst, mine)
+    else:
+        allst = [mine]
+    allst = torch.stack(allst).cpu().numpy()
+    stages = {k: {"max_s": float(allst[:, i].max()), "min_s": float(allst[:, i].min())} for i, k in enumerate(stage_names)}
+    gather_bytes = args.steps * loop.n_total * loop.d.embed_dim * 4
+    stages["allgather"]["bytes_received_per_rank"] = gather_bytes * (ws - 1) // max(ws, 1)
+    stages["allgather"]["achieved_GBps_per_rank"] = (gather_bytes * (ws - 1) / ws / stages["allgather"]["max_s"] / 1e9) if ws > 1 and stages["allgather"]["max_s"] > 0 else None
     f16_loop = None
     if args.mode == "identical":
         # the same loop once more WITHOUT the guarantee (the f16 towers' own lists), outside the timed region: what the index guarantee costs
@@ -562,7 +635,7 @@ def main():
         "unit": "images/sec",
         "n_gpus": ws, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "Flowers102-shaped CoOp textual-prompt SSL pseudolabel+prompt-step loop, ViT-B/16 (BASELINE.json configs[1])",
                    "pseudolabel_mode": args.mode,
@@ -572,7 +645,7 @@ def main():
                                        "exact mode on this very pool is checked in the `exact` block and asserted in tests/test_gpu_identical.py)")
                                       if args.mode == "identical" else
                                       "none: f16 lists (boundary items may differ from the fp32 scan's); run with --mode identical for the guarantee",
-                   "pool_images_per_gpu": args.pool, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
+                   "pool_images_per_gpu": args.pool, "pool_images_total": loop.n_total, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
                    "encode_chunk": args.chunk, "encode_streams": args.streams, "train_batch_per_gpu": args.batch, "parallelism": f"dp{ws}",
                    "selected_pairs": int(loop.m_selected), "prompt_steps_per_pass": int(loop.train_steps),
                    "text_positions_encoded": seq, "prompt_step_hip_graph": bool(args.graph),
@@ -584,6 +657,7 @@ def main():
                    "collectives": "RCCL all_gather_into_tensor of [pool, 512] f32 embeddings per pass + all_reduce of the 32 KB prompt gradient per step"
                                   if not on_host else "gloo through host memory (GRIP_DIST_BACKEND=gloo)"},
         "ranks_seen": seen,
+        "stage_seconds_over_ranks": stages,
         "pseudolabel_images_per_sec": images / loop.t_pl if loop.t_pl else None,
         "identical_images_per_sec": (images / loop.t_pl if loop.t_pl else None) if args.mode == "identical" else None,
         "f16_mode_loop": f16_loop,
@@ -602,6 +676,12 @@ def main():
         "roofline": {
             "bound": "mfma", "kernel": kname(dom), "kernel_instantiation": full_kernel_name(dom),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "clock_ghz_sustained": clocks["sclk_mhz_mean"] / 1e3 if clocks else None,
+            "frac_at_sustained_clock": achieved / (peak * clocks["sclk_mhz_mean"] / PEAK_CLOCK_MHZ) if clocks else None,
+            "clock_power": clocks,
+            "clock_note": f"shader clock / package power sampled at 20 Hz from the amdgpu hwmon files over the whole timed region (all kernels, host gaps "
+                          f"included); `peak` is quoted at {PEAK_CLOCK_MHZ / 1e3:.1f} GHz, frac_at_sustained_clock scales it to the mean clock measured; "
+                          "profiles/r03_clock_power.csv holds the trace with the pure-MFMA zero / random-operand loops beside it",
             "traffic": traffic, "mfma_util_pmc": mfma_util,
             "traffic_source": f"{TRAFFIC_FILE}: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES), "
                               "read from the committed file, not measured in this run; null when the file does not describe exactly `kernel_instantiation`",
@@ -613,11 +693,13 @@ def main():
     }
     if ws == 1:
         if not args.no_exact:
+            clock_marker("exact")
             out["exact"] = exact_block(loop, lib)
         if not args.no_secondary:
             del loop.pool
             loop.pool = synth_pool(64, loop.d.image_resolution, device, 99)
             torch.cuda.empty_cache()
+            clock_marker("secondary")
             out["secondary"] = secondary_block(loop, lib)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -23,7 +23,10 @@ def world():
 def init_from_env(backend=None):
     """Initialise from torchrun's RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* when present."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or is_dist():
+    # a 1-rank group is only formed when the C ABI's own communicator is asked for (GRIP_NATIVE_COMM=1 under a launcher): that is
+    # how its RCCL calls run inside the real data path on a one-GPU box
+    solo_native = ws == 1 and os.environ.get("GRIP_NATIVE_COMM") == "1" and "RANK" in os.environ
+    if (ws <= 1 and not solo_native) or is_dist():
         return world()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -39,6 +42,32 @@ def local_device_index():
     """GPU of this rank: LOCAL_RANK, or 0 for every rank when GRIP_SINGLE_DEVICE=1 (several ranks sharing one GPU
     over gloo: how the N > 1 path is exercised on a one-GPU box)."""
     return 0 if os.environ.get("GRIP_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def pin_to_gpu_numa_node(device_index):
+    """Restrict this process to the CPUs of the NUMA node its GPU hangs off (sysfs: the PCI device's numa_node -> the node's
+    cpulist), so the rank's host side -- the sequential leaderboard scan, kernel launches, the staging copies of the input
+    pipeline -- runs next to its GPU instead of across the socket interconnect.  Returns the node number, or None when the
+    topology cannot be read (containers often hide it) or GRIP_NUMA_PIN=0; never raises."""
+    if os.environ.get("GRIP_NUMA_PIN", "1") == "0":
+        return None
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
 
 
 def _via_host():
@@ -73,9 +102,16 @@ class NativeComm:
             self.lib.grip_comm_destroy(self.handle)
             self.handle = None
 
+    def _trace(self, what):
+        path = os.environ.get("GRIP_COMM_TRACE")      # developer / test switch: one line per native collective
+        if path:
+            with open(path, "a") as f:
+                f.write(what + "\n")
+
     def allgather(self, local, per):
         from . import native
         import ctypes
+        self._trace(f"allgather rows={per} ranks={self.ws}")
         local = local.contiguous()
         out = torch.empty(self.ws * per, local.shape[1], dtype=torch.float32, device=local.device)
         native.check(self.lib.grip_allgather_embeddings(self.handle, ctypes.c_void_p(local.data_ptr()), ctypes.c_void_p(out.data_ptr()), per,
@@ -85,6 +121,7 @@ class NativeComm:
     def allreduce_mean_(self, flat):
         from . import native
         import ctypes
+        self._trace(f"allreduce n={flat.numel()} ranks={self.ws}")
         native.check(self.lib.grip_allreduce_mean(self.handle, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return flat
@@ -119,7 +156,7 @@ def allgather_rows(local, n_total, per):
     """local [<= per, E] rows of this rank's shard -> [n_total, E] in global order on every rank.
     Pads the last shard to `per` rows and drops the padding after the gather."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and native_comm() is None:
         return local[:n_total]
     e = local.shape[1]
     if local.shape[0] != per:
@@ -161,7 +198,7 @@ def allgather_selected(local_rows, idx, n_total):
 def allreduce_mean_(tensors):
     """In-place mean all-reduce of the (tiny) prompt gradients, flattened into one message."""
     rank, ws = world()
-    if ws == 1 or not tensors:
+    if (ws == 1 and native_comm() is None) or not tensors:
         return
     flat = torch.cat([t.reshape(-1) for t in tensors])
     if _via_host() and flat.is_cuda:

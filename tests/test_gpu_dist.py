@@ -31,10 +31,18 @@ with torch.no_grad():
     emb_p = pl.encode_pool(m.visual.tower, x, chunk=16, prefix=prefix)
     txt = m.encode_text(clip.tokenize(["a", "b c", "d e f", "g"]).cuda())
 lists = pl.pseudolabel_from_features(emb, txt, 100.0, [f"p{i:03d}" for i in range(n)], [0, 1, 2, 3], 5)
+# screen and refine across ranks: each rank re-encodes the marked rows of its own shard, one small all-gather per round
+twin = m.exact_twin()
+with torch.no_grad():
+    txt32 = twin.encode_text(clip.tokenize(["a", "b c", "d e f", "g"]).cuda())
+    e32 = twin.encode_image(x.cuda())
+ident = pl.identical_lists(m.visual.tower, twin.visual.tower, x, txt32, 100.0, [f"p{i:03d}" for i in range(n)], [0, 1, 2, 3], 5, chunk=16, exact_chunk=8)
+exact = pl.pseudolabel_from_features(e32, txt32, 100.0, [f"p{i:03d}" for i in range(n)], [0, 1, 2, 3], 5)
+refined = (pl.LAST_REFINE_STATS["rows_refined"], pl.LAST_REFINE_STATS["rows_refined_this_rank"])
 g = torch.ones(3, device="cuda") * (rank + 1)
 gdist.allreduce_mean_([g])
 with open(os.environ["GRIP_OUT"] + f".{rank}", "wb") as f:
-    pickle.dump({"emb": emb.cpu(), "emb_p": emb_p.cpu(), "lists": lists, "g": g.cpu(), "ws": ws}, f)
+    pickle.dump({"emb": emb.cpu(), "emb_p": emb_p.cpu(), "lists": lists, "g": g.cpu(), "ws": ws, "ident": ident, "exact": exact, "refined": refined}, f)
 gdist.barrier()
 '''
 
@@ -69,6 +77,9 @@ def test_sharded_encode_allgather_matches_single_process(tmp_path):
     assert torch.equal(r0["emb"], ref["emb"]) and torch.equal(r1["emb"], ref["emb"])     # rows are independent of the chunking
     assert torch.equal(r0["emb_p"], ref["emb_p"]) and torch.equal(r1["emb_p"], ref["emb_p"]) and not torch.equal(ref["emb_p"], ref["emb"])
     assert r0["lists"] == ref["lists"] and r1["lists"] == ref["lists"]
+    # identical mode: the exact lists on one rank and on two, with the re-encoding work split between the shards
+    assert ref["ident"] == ref["exact"] and r0["ident"] == ref["exact"] and r1["ident"] == ref["exact"]
+    assert r0["refined"][0] == r1["refined"][0] == r0["refined"][1] + r1["refined"][1] and ref["refined"][0] == ref["refined"][1]
     assert torch.allclose(r0["g"], torch.full((3,), 1.5)) and torch.allclose(r1["g"], torch.full((3,), 1.5))
 
 
@@ -84,6 +95,33 @@ def test_bench_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["selected_pairs"] > 0 and "cpu_baseline" not in d
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0
+    # the default mode carries the index guarantee on N ranks too (each rank re-encodes the marked rows of its own shard)
+    assert d["config"]["pseudolabel_mode"] == "identical" and d["identical"]["rows_reencoded_exactly"] > 0 and d["identical_images_per_sec"] > 0
+    st = d["stage_seconds_over_ranks"]
+    assert set(st) == {"encode_f16", "allgather", "head_scan", "refine_exact", "train"} and all(v["max_s"] >= v["min_s"] >= 0 for v in st.values())
+    assert [r["rank"] for r in d["ranks_seen"]] == [0, 1]
+
+
+def test_bench_strong_scaling_mode_and_native_comm_single_rank(tmp_path):
+    """--strong splits --pool over the ranks (2 x 660); and a 1-rank run under a launcher with GRIP_NATIVE_COMM=1 sends the bench's
+    all-gather and gradient all-reduce through the C ABI's own RCCL communicator (grip_allgather_embeddings / grip_allreduce_mean)."""
+    env = _env(tmp_path)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--pool", "1320", "--strong", "--chunk", "220"], env=env, capture_output=True, text=True, timeout=1200, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["pool_images_per_gpu"] == 660 and d["config"]["pool_images_total"] == 1320
+    env1 = dict(os.environ, PYTHONPATH=REPO, GRIP_NATIVE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GRIP_COMM_TRACE=str(tmp_path / "comm.log"))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                          "--pool", "1320", "--chunk", "220", "--no-exact", "--no-secondary", "--no-cpu-baseline"], env=env1, capture_output=True, text=True,
+                         timeout=1200, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    calls = open(tmp_path / "comm.log").read()
+    assert "allgather" in calls and "allreduce" in calls, calls
 
 
 def test_native_rccl_communicator_single_rank():
