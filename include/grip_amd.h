@@ -170,6 +170,34 @@ int grip_weighted_ce(const float* logits, const int32_t* labels, const float* ro
                      float* loss, float* grad_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * UPTModel's prompt mixer (models/prompts_models.py:99-119 construct it, :129-146 run it): proj_coop_pre / proj_vpt_pre (Linear
+ * to `dim`), clip.model.Transformer(width = dim, layers = 1, heads = 1) over the sequence cat((coop, vpt), dim 0) = [2, P, dim]
+ * (sequence length 2, batch P), the .to(float16) round trip of :138-145, proj_coop_post / proj_vpt_post.  The only trainable
+ * weights on the path: grip_upt_mixer_backward returns the gradient of EVERY tensor of the struct (float32 parameters; the
+ * reference's float16 branch, multimodal_prompt.py:46, stays on the host framework's kernels).
+ * One struct describes the tensors (forward: values; backward's `grads`: buffers of the same shapes that receive the gradients):
+ *   coop [P, text_width], vpt [P, vision_width]                 coop_embeddings / vpt_embeddings (P = n_prompt tokens each)
+ *   coop_pre_w [dim, text_width], coop_pre_b [dim]              proj_coop_pre;   vpt_pre_* likewise with vision_width
+ *   ln1_g, ln1_b [dim]; in_w [3 dim, dim], in_b [3 dim]; out_w [dim, dim], out_b [dim]      resblocks.0.ln_1 / attn.in_proj_* / attn.out_proj
+ *   ln2_g, ln2_b [dim]; fc_w [4 dim, dim], fc_b [4 dim]; proj_w [dim, 4 dim], proj_b [dim]  resblocks.0.ln_2 / mlp.c_fc / mlp.c_proj
+ *   coop_post_w [text_width, dim], coop_post_b [text_width]     proj_coop_post;  vpt_post_* likewise
+ * forward:  coop_out [P, text_width], vpt_out [P, vision_width] (what CustomTextEncoder / CustomImageEncoder receive as prompts).
+ * backward: d_coop_out / d_vpt_out = the prompt gradients grip_text_backward_prefix / grip_vit_backward_prefix returned; must follow
+ * a forward on the same workspace (it holds the saved activations).  The gradient entering the fp16 tensor is rounded to fp16 as
+ * autograd does.  All device pointers f32; work is enqueued on `stream`; no atomics (bit-reproducible). */
+typedef struct {
+    int32_t n_prompt, text_width, vision_width, dim;
+    float *coop, *vpt;
+    float *coop_pre_w, *coop_pre_b, *vpt_pre_w, *vpt_pre_b;
+    float *ln1_g, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_g, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b;
+    float *coop_post_w, *coop_post_b, *vpt_post_w, *vpt_post_b;
+} grip_upt_mixer;
+int grip_upt_mixer_workspace(int n_prompt, int text_width, int vision_width, int dim, size_t* bytes);
+int grip_upt_mixer_forward(const grip_upt_mixer* m, float* coop_out, float* vpt_out, void* workspace, size_t workspace_bytes, void* stream);
+int grip_upt_mixer_backward(const grip_upt_mixer* m, const float* d_coop_out, const float* d_vpt_out, const grip_upt_mixer* grads,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * CLIP preprocessing of one decoded image: the `_transform` the reference applies per item on the host
  * (data/dataset.py:64-79 via clip.load's preprocess): Resize(n_px, BICUBIC) -> CenterCrop(n_px) -> ToTensor -> Normalize.
  * Bit-exact with Pillow's 8-bit bicubic resample; only the cropped rows / columns are produced.

@@ -447,6 +447,47 @@ class WeightedCEFn(torch.autograd.Function):
         return grad * g, None, None
 
 
+class UptMixerFn(torch.autograd.Function):
+    """UPTModel's prompt mixer (models/prompts_models.py:129-146) on the native kernels (csrc/mixer.hip): forward and the
+    gradients of all 22 tensors -- the two prompt embeddings, the four projections and the one-block transformer."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        lib = native.lib()
+        ts = [t.detach().contiguous().float() for t in tensors]
+        coop, vpt = ts[0].reshape(-1, ts[0].shape[-1]), ts[1].reshape(-1, ts[1].shape[-1])
+        P, dt, dv, D = coop.shape[0], coop.shape[1], vpt.shape[1], ts[2].shape[0]
+        if vpt.shape[0] != P:
+            raise native.GripError(f"UPT mixer: {P} text prompt tokens but {vpt.shape[0]} visual ones (the reference concatenates them along dim 0)")
+        dev = coop.device
+        nbytes = c_size_t()
+        native.check(lib.grip_upt_mixer_workspace(P, dt, dv, D, byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        coop_out = torch.empty(P, dt, dtype=torch.float32, device=dev)
+        vpt_out = torch.empty(P, dv, dtype=torch.float32, device=dev)
+        m = native.UptMixer(P, dt, dv, D, *[t.data_ptr() for t in ts])
+        native.check(lib.grip_upt_mixer_forward(byref(m), _ptr(coop_out), _ptr(vpt_out), _ptr(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(*ts)
+        ctx.ws, ctx.dims = ws, (P, dt, dv, D)
+        ctx.shapes = [t.shape for t in tensors]
+        ctx.dtypes = [t.dtype for t in tensors]
+        return coop_out, vpt_out
+
+    @staticmethod
+    def backward(ctx, d_coop, d_vpt):
+        lib = native.lib()
+        ts = ctx.saved_tensors
+        P, dt, dv, D = ctx.dims
+        dev = ts[0].device
+        d_coop = torch.zeros(P, dt, device=dev) if d_coop is None else d_coop.contiguous().float()
+        d_vpt = torch.zeros(P, dv, device=dev) if d_vpt is None else d_vpt.contiguous().float()
+        grads = [torch.empty_like(t) for t in ts]
+        m = native.UptMixer(P, dt, dv, D, *[t.data_ptr() for t in ts])
+        g = native.UptMixer(P, dt, dv, D, *[t.data_ptr() for t in grads])
+        native.check(lib.grip_upt_mixer_backward(byref(m), _ptr(d_coop), _ptr(d_vpt), byref(g), _ptr(ctx.ws), ctx.ws.numel(), _stream()))
+        return tuple(gr.reshape(sh).to(dtp) for gr, sh, dtp in zip(grads, ctx.shapes, ctx.dtypes))
+
+
 def leaderboard_scan(probs, pred, path_rank, k):
     """Host scan (exact, sequential).  probs [n,c] f32 CPU, pred [n] int32 CPU, path_rank [n] int64 CPU."""
     import numpy as np

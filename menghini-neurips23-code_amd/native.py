@@ -35,6 +35,15 @@ class PreprocessItem(ctypes.Structure):
                 ("tmp", c_void_p), ("out", c_void_p)]
 
 
+MIXER_TENSORS = ("coop", "vpt", "coop_pre_w", "coop_pre_b", "vpt_pre_w", "vpt_pre_b", "ln1_g", "ln1_b", "in_w", "in_b", "out_w", "out_b",
+                 "ln2_g", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b", "coop_post_w", "coop_post_b", "vpt_post_w", "vpt_post_b")
+
+
+class UptMixer(ctypes.Structure):
+    """grip_upt_mixer (include/grip_amd.h)."""
+    _fields_ = [(n, c_int32) for n in ("n_prompt", "text_width", "vision_width", "dim")] + [(n, c_void_p) for n in MIXER_TENSORS]
+
+
 _SIGS = {
     "grip_last_error": (ctypes.c_char_p, []),
     "grip_abi_version": (c_int, []),
@@ -51,6 +60,9 @@ _SIGS = {
     "grip_cosine_head": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_cosine_head_backward": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_weighted_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "grip_upt_mixer_workspace": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_size_t)]),
+    "grip_upt_mixer_forward": (c_int, [POINTER(UptMixer), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "grip_upt_mixer_backward": (c_int, [POINTER(UptMixer), c_void_p, c_void_p, POINTER(UptMixer), c_void_p, c_size_t, c_void_p]),
     "grip_preprocess_image": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_preprocess_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
