@@ -331,14 +331,24 @@ def cpu_model_string():
 
 def cpu_baseline(args):
     """The CPU oracle (oracle/, a port of the reference path: kind "port") on a bounded sample of the same workload
-    (BASELINE.md section 3).
+    (BASELINE.md section 3), within a wall-clock budget (--cpu-budget seconds, default 40) so that the default run stays short on
+    any host.
     R-mode = the reference loop of utils/clip_pseudolabels.py:31-41: batch 1, the full clip_model(image, text) per image, i.e.
-    the image tower at batch 1 plus all C class prompts re-encoded for every image.  The image tower is timed on every one
-    of the --cpu-sample (>= 64) images; the per-image text re-encode -- the same 102 prompts every time, ~95 % of the loop's
-    FLOPs -- is timed on --cpu-text-reps of them (full clip_model calls) and its mean is applied to the rest, which keeps
-    the default run to about a minute of CPU time instead of six.  --cpu-full times the literal loop on every image.
-    B-mode (reported beside it) = batch 16 with text features cached, averaged over >= 3 batches."""
+    the image tower at batch 1 plus all C class prompts re-encoded for every image.  Full calls are timed first (at least one, at
+    most --cpu-text-reps, a third of the budget), then the image tower alone at batch 1 on further images (at most --cpu-sample,
+    another third); the per-image text re-encode -- the same 102 prompts every time, ~95 % of the loop's FLOPs -- is the
+    difference of the two means.  R-mode images/sec = 1 / (mean image time + text share).  --cpu-full times the literal loop on
+    every sampled image instead.  B-mode (reported beside it) = batch 16 with text features cached.
+    Threads: the CPUs this process may actually use (affinity mask and cgroup quota), not the host's logical CPU count."""
     import importlib
+
+    from grip_amd.data.decode import usable_cpus
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))      # undo the GPU-side NUMA pin for the host measurement
+    except OSError:
+        pass
+    threads = max(1, min(torch.get_num_threads(), usable_cpus()))
+    torch.set_num_threads(threads)
     oclip = importlib.import_module("oracle.clip")
     t0 = time.perf_counter()
     om, _ = oclip.load(MODEL)
@@ -346,40 +356,45 @@ def cpu_baseline(args):
     C = args.classes
     tok = synth_tokens(C, 0)
     g = torch.Generator().manual_seed(1234)
-    n_r = max(args.cpu_sample, 1)
-    reps = n_r if args.cpu_full else max(1, min(args.cpu_text_reps, n_r))
-    x = torch.randn(max(n_r, 48), 3, 224, 224, generator=g)
+    budget = float(args.cpu_budget)
+    n_max = max(args.cpu_sample, 1)
+    x = torch.randn(max(n_max, 48), 3, 224, 224, generator=g)
     with torch.no_grad():
         om(x[:1], tok[:2])   # warm-up
-        t_full = []
-        for i in range(reps):            # the literal loop body: both towers + softmax + argmax
+        t_full, start = [], time.perf_counter()
+        reps_max = n_max if args.cpu_full else max(1, min(args.cpu_text_reps, n_max))
+        while len(t_full) < reps_max and (not t_full or args.cpu_full or time.perf_counter() - start < budget / 3):
+            i = len(t_full)      # the literal loop body: both towers + softmax + argmax
             t0 = time.perf_counter()
             li, _ = om(x[i:i + 1], tok)
             li.softmax(dim=-1).argmax(dim=1)
             t_full.append(time.perf_counter() - t0)
-        t_img = []
-        for i in range(n_r):             # the image tower at batch 1 on every sampled image
+        t_img, start = [], time.perf_counter()
+        while len(t_img) < n_max and (len(t_img) < 4 or time.perf_counter() - start < budget / 3):
+            i = len(t_img)       # the image tower at batch 1
             t0 = time.perf_counter()
             om.encode_image(x[i:i + 1])
             t_img.append(time.perf_counter() - t0)
-        t_text = max(float(np.mean(t_full)) - float(np.mean(t_img[:reps])), 0.0)    # the re-encode share of a full call
-        t_r = float(np.sum(t_img)) + n_r * t_text if not args.cpu_full else float(np.sum(t_full))
+        reps, n_r = len(t_full), len(t_img)
+        t_text = max(float(np.mean(t_full)) - float(np.mean(t_img[:max(reps, 4)])), 0.0)    # the re-encode share of a full call
+        per_image = float(np.mean(t_img)) + t_text if not args.cpu_full else float(np.mean(t_full))
         t0 = time.perf_counter()
         om.encode_text(tok)
         t_txt = time.perf_counter() - t0
-        t_b = []
-        for b in range(3):
+        t_b, start = [], time.perf_counter()
+        while len(t_b) < 3 and (not t_b or time.perf_counter() - start < budget / 3):
+            b = len(t_b)
             t0 = time.perf_counter()
             om.encode_image(x[16 * b:16 * b + 16])
             t_b.append(time.perf_counter() - t0)
     b_ips = 16 * len(t_b) / float(np.sum(t_b))
     return {
-        "value": n_r / t_r, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-        "cpu_model": cpu_model_string(), "cpu_count": os.cpu_count(),
-        "sample": f"R-mode (reference loop: batch 1, {C} class prompts re-encoded per image) on {n_r} images: image tower timed on all {n_r} "
-                  f"({np.mean(t_img) * 1e3:.0f} ms mean), full clip_model(image, text) calls timed on {reps} of them ({np.mean(t_full):.2f} s mean) "
+        "value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "kind": "port",
+        "cpu_model": cpu_model_string(), "cpu_count": os.cpu_count(), "usable_cpus": usable_cpus(),
+        "sample": f"R-mode (reference loop: batch 1, {C} class prompts re-encoded per image): image tower timed on {n_r} images "
+                  f"({np.mean(t_img) * 1e3:.0f} ms mean), full clip_model(image, text) calls timed on {reps} ({np.mean(t_full):.2f} s mean) "
                   f"and their text share applied to every image; B-mode (batch 16, text cached, {len(t_b)} batches) = {b_ips:.2f} images/sec, "
-                  f"one text encode of {C} prompts {t_txt:.2f} s; oracle build {build_s:.0f} s",
+                  f"one text encode of {C} prompts {t_txt:.2f} s; oracle build {build_s:.0f} s; {threads} torch threads; wall budget {budget:.0f} s",
         "r_mode_images": n_r, "r_mode_full_calls_timed": reps,
         "b_mode_images_per_sec": b_ips, "b_mode_batches": len(t_b),
     }
@@ -488,6 +503,73 @@ def secondary_block(loop, lib):
     return out
 
 
+def from_files_block(loop):
+    """SURVEY.md 8f-2 (the reference's data/dataset.py:56-89 + utils/clip_pseudolabels.py:31-33: PIL open + transform per image on
+    the host): images/sec from JPEG FILES to embeddings -- parallel decode on the host (threads, and worker processes around a
+    shared-memory segment), one upload + one batched preprocess launch pair per chunk, the f16 ViT-B/16 encode of chunk i running
+    while chunk i + 1 decodes.  Files are synthetic JPEGs of ImageNet-like sizes written to a temp directory outside every timed
+    region; each configuration is timed over two passes after a warm-up pass."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
+    from PIL import Image
+
+    from grip_amd.data.decode import default_processes, usable_cpus
+    from grip_amd.preprocess import ClipPreprocess
+    n, chunk = 1024, 512
+    d = tempfile.mkdtemp(prefix="grip_bench_files_")
+    g = np.random.RandomState(0)
+    paths = []
+    try:
+        for i in range(n):      # low-frequency content so that the JPEG sizes are realistic
+            h, w = int(g.choice([375, 333, 500, 480])), int(g.choice([500, 400, 640]))
+            base = g.randint(0, 256, size=(h // 16 + 1, w // 16 + 1, 3)).astype(np.uint8)
+            p = os.path.join(d, f"{i:05d}.jpg")
+            Image.fromarray(base).resize((w, h), Image.BICUBIC).save(p, quality=90)
+            paths.append(p)
+        pre = ClipPreprocess(loop.d.image_resolution, loop.device)
+        tower = loop.m.visual.tower
+        emb = torch.empty(chunk, loop.d.embed_dim, dtype=torch.float32, device=loop.device)
+        spans = [(lo, min(lo + chunk, n)) for lo in range(0, n, chunk)]
+        bg = ThreadPoolExecutor(max_workers=1)
+
+        def one_pass(encode, **kw):
+            fut = bg.submit(pre.decode_chunk, paths[spans[0][0]:spans[0][1]], **kw)
+            for i, (lo, hi) in enumerate(spans):
+                h = fut.result()
+                if i + 1 < len(spans):
+                    fut = bg.submit(pre.decode_chunk, paths[spans[i + 1][0]:spans[i + 1][1]], **kw)
+                x = pre.finish_chunk(h)
+                if encode:
+                    with torch.no_grad():
+                        tower.encode_chunks(x, emb, 0, hi - lo, hi - lo, streams=1)
+            torch.cuda.synchronize()
+
+        def rate(encode, passes=2, **kw):
+            one_pass(encode, **kw)
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                one_pass(encode, **kw)
+            return passes * n / (time.perf_counter() - t0)
+
+        procs = default_processes()
+        out = {"files": n, "chunk": chunk, "usable_cpus": usable_cpus(), "host_cpu_count": os.cpu_count(),
+               "threads_8_decode_preprocess_encode": rate(True, workers=8, processes=0)}
+        if procs > 0:
+            out["decode_processes"] = procs
+            out["processes_decode_preprocess"] = rate(False, workers=8, processes=procs)
+            out["processes_decode_preprocess_encode"] = rate(True, workers=8, processes=procs)
+            out["per_cpu_images_per_sec"] = out["processes_decode_preprocess_encode"] / max(usable_cpus(), 1)
+        out["images_per_sec"] = out.get("processes_decode_preprocess_encode", out["threads_8_decode_preprocess_encode"])
+        out["note"] = ("JPEG files -> embeddings; decode is host-CPU bound (libjpeg-turbo through Pillow, bit-identical to the reference's transform): "
+                       "the rate scales with the CPUs the container may use, the encoder alone runs at `pseudolabel_images_per_sec`")
+        pre.close()
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -512,6 +594,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--cpu-sample", type=int, default=64, help="images of the R-mode CPU baseline (BASELINE.md section 3: >= 64)")
     ap.add_argument("--cpu-text-reps", type=int, default=6, help="how many of them time the full clip_model(image, text) call (the per-image text re-encode)")
+    ap.add_argument("--cpu-budget", type=float, default=40.0, help="wall-clock seconds the CPU baseline may take (it stops sampling when they are spent)")
     ap.add_argument("--cpu-full", action="store_true", help="time the literal R-mode loop on every sampled image (~6 s each)")
     ap.add_argument("--lookahead", type=int, default=13,
                     help="CoOp steps whose frozen image-tower forward is batched into one encode (steps.lookahead_image_features); 1 = encode inside every step")
@@ -701,6 +784,10 @@ def main():
             torch.cuda.empty_cache()
             clock_marker("secondary")
             out["secondary"] = secondary_block(loop, lib)
+            try:
+                out["secondary"]["from_files"] = from_files_block(loop)
+            except Exception as e:      # the input pipeline is a NEXT row: its failure must not take the bench line down
+                out["secondary"]["from_files"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out), flush=True)

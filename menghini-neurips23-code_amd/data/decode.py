@@ -58,11 +58,38 @@ def default_processes():
 
 class Packed:
     """Decoded images of one chunk inside a staging buffer: `offsets[i]` (bytes), `shapes[i]` = (H, W); image i occupies
-    H*W*3 bytes at its offset.  `used` = high-water mark of the buffer."""
-    __slots__ = ("offsets", "shapes", "used")
+    H*W*3 bytes at its offset.  `used` = high-water mark of the buffer.  `regions` (process back end): the spans
+    (first byte, bytes written, first image, one past the last image) each worker filled inside its own part of the segment --
+    the gaps between them hold nothing, `compact_into` copies only the spans."""
+    __slots__ = ("offsets", "shapes", "used", "regions")
 
-    def __init__(self, offsets, shapes, used):
-        self.offsets, self.shapes, self.used = offsets, shapes, used
+    def __init__(self, offsets, shapes, used, regions=None):
+        self.offsets, self.shapes, self.used, self.regions = offsets, shapes, used, regions
+
+    def compact_into(self, src, dst, pool=None):
+        """Copy the decoded bytes from the shared segment `src` into the staging buffer `dst` WITHOUT the gaps between the
+        workers' regions (the segment is sized 1.5x and split evenly: copying / uploading it whole moves ~1.5x the bytes) and
+        return the Packed that describes `dst`.  Region copies run on `pool` (a ThreadPoolExecutor) when given."""
+        if not self.regions:
+            dst[:self.used] = src[:self.used]
+            return self
+        offsets = self.offsets.copy()
+        jobs, at = [], 0
+        for base, nbytes, lo, hi in self.regions:
+            if nbytes:
+                jobs.append((base, nbytes, at))
+                offsets[lo:hi] += at - base
+                at += nbytes
+
+        def copy(job):
+            base, nbytes, to = job
+            dst[to:to + nbytes] = src[base:base + nbytes]
+        if pool is not None and len(jobs) > 1:
+            list(pool.map(copy, jobs))
+        else:
+            for j in jobs:
+                copy(j)
+        return Packed(offsets, self.shapes, at)
 
 
 def decode_threads(paths, buf, pool):
@@ -176,7 +203,9 @@ class ProcessDecoder:
             for w, rep in enumerate(replies):
                 if "error" in rep:
                     raise RuntimeError(f"decode worker {w}: {rep['error']}")
+            regions = []
             for w, rep in enumerate(replies[:nw]):
+                end = w * region
                 for j, (off, h, wd) in enumerate(rep["items"]):
                     i = bounds[w] + j
                     shapes[i] = (h, wd)
@@ -184,10 +213,12 @@ class ProcessDecoder:
                         overflow[i] = None
                     else:
                         offsets[i] = off
-                        used = max(used, off + _round(h * wd * 3))
+                        end = max(end, off + _round(h * wd * 3))
+                regions.append((w * region, end - w * region, bounds[w], bounds[w + 1]))
+                used = max(used, end)
         for i in overflow:
             overflow[i] = decode_file(paths[i])
-        return Packed(offsets, shapes, used), overflow
+        return Packed(offsets, shapes, used, regions), overflow
 
     def close(self):
         for p in self.workers:

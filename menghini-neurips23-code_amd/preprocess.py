@@ -213,13 +213,12 @@ class ClipPreprocess:
             if dec.segs[0].size < n * hint * 1.1:
                 dec.ensure(0, int(n * hint * 1.5))
             packed, overflow = dec.decode(paths, 0)
-            # shared segment -> page-locked staging buffer (a plain copy, split over a few threads; the segment is free again at once).
-            # The segment itself is NOT registered with the HIP runtime for DMA.
-            k, hv = self._staging(packed.used + 1)
-            src, step = dec.slot_view(0), max(1 << 22, (packed.used + 3) // 4)
-            spans = [(o, min(o + step, packed.used)) for o in range(0, packed.used, step)]
+            # shared segment -> page-locked staging buffer: one plain copy per worker region, gaps between the regions left behind
+            # (Packed.compact_into), split over a few threads; the segment is free again at once.  The segment itself is NOT
+            # registered with the HIP runtime for DMA.
+            k, hv = self._staging(sum(r[1] for r in packed.regions) + 1 if packed.regions else packed.used + 1)
             cp = self.__dict__.get("_copy_pool") or self.__dict__.setdefault("_copy_pool", D.make_thread_pool(4))
-            list(cp.map(lambda se: hv.__setitem__(slice(se[0], se[1]), src[se[0]:se[1]]), spans))
+            packed = packed.compact_into(dec.slot_view(0), hv, cp)
             if n:
                 total = packed.used + sum(a.nbytes for a in overflow.values())
                 self.__dict__["_bytes_per_image"] = max(hint if not overflow else 0, total // n + 1)

@@ -132,3 +132,49 @@ def test_pseudolabel_top_k_default_mode_is_identical_and_f16_mode_is_plain(tmp_p
     pseudolabel_top_k(types.SimpleNamespace(LEARNING_PARADIGM="ul", MODEL="visual_fpl_f16"), "EuroSAT", 16, "a photo of a {}", ds, classnames, None, m,
                       label_to_idx, "cuda", "ViT-B/32", 500)
     assert pl.LAST_REFINE_STATS is None and len(ds.filepaths) > 0
+
+
+def test_exact_and_identical_lists_on_the_10000_image_reference_fixture(vitb16):
+    """tests/golden/exact_vitb16_c102_n10000.npz: what the REFERENCE's compute_pseudo_labels returned for 10 000 structured images
+    x 102 classes on the CPU oracle (oracle/gen_golden_exact.py 10000, ~40 CPU-minutes offline), with the fp32 probabilities
+    it compared.  The exact mode must reproduce the probabilities to 1e-4 relative and the lists (k = 3, 16, label-everything) up
+    to transpositions of scores closer than one fp32 logit ulp; the default screen-and-refine path must return exactly the exact
+    mode's lists."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import grip_amd  # noqa: F401
+    from grip_amd import engine, pseudolabels as pl
+    from grip_amd.data.synthetic import pool_paths, structured_images
+    from test_gpu_exact import assert_lists_identical
+    fx = np.load(os.path.join(REPO, "tests", "golden", "exact_vitb16_c102_n10000.npz"))
+    o_probs = fx["probs"]
+    n, C = o_probs.shape
+    assert (n, C) == (10000, 102)
+    m, twin = vitb16, vitb16.exact_twin()
+    seed = int(fx["seed"])
+    pool = torch.empty(n, 3, 224, 224, device="cuda")
+    with ThreadPoolExecutor(max_workers=8) as ex:       # the counter-RNG images regenerate block by block (64 per block), in parallel
+        for lo, x in ex.map(lambda lo: (lo, structured_images(seed, lo, min(lo + 64, n), 224)), range(0, n, 64)):
+            pool[lo:lo + x.shape[0]] = x.cuda()
+    tok = torch.from_numpy(fx["tokens"]).cuda()
+    paths = pool_paths(n)
+    labels = list(range(C))
+    scale = m.logit_scale.exp().item()
+    with torch.no_grad():
+        txt = twin.encode_text(tok)
+        e32 = torch.empty(n, 512, device="cuda")
+        twin.visual.tower.encode_chunks(pool, e32, 0, n, 250, streams=1)
+    _, p32, _, a32 = engine.cosine_head(e32, txt, scale)
+    p32h, a32h = p32.cpu().numpy(), a32.cpu().numpy()
+    rel = (np.abs(p32h.astype(np.float64) - o_probs) / o_probs).max()
+    assert rel <= 1e-4, f"exact-mode probabilities are {rel:.2e} (relative) from the fp32 oracle's"
+    for k in (3, 16, 10000000):
+        ref_lists = json.loads(str(fx[f"lists_k{k}"]))
+        exact = pl.leaderboard(p32h, a32h, paths, labels, k)
+        swapped = assert_lists_identical(exact, (ref_lists[0], ref_lists[1]), o_probs, paths, labels, f"n10000 exact k={k}")
+        got = pl.identical_lists(m.visual.tower, twin.visual.tower, pool, txt, scale, paths, labels, k, chunk=1000)
+        st = pl.LAST_REFINE_STATS
+        assert (list(got[0]), list(got[1])) == (list(exact[0]), list(exact[1])), f"n10000 k={k}: screen-and-refine differs from the exact mode"
+        print(f"n10000 k={k}: {len(exact[0])} pairs, max relative dp {rel:.2e}, reference margin {float(fx[f'margin_k{k}']):.2e}, "
+              f"tie transpositions vs the reference {swapped}, {st['rows_refined']} rows re-encoded")
+        assert swapped <= 4

@@ -242,3 +242,21 @@ def test_decode_backends_pack_the_same_pixels(tmp_path):
     finally:
         dec.close()
     assert set(os.listdir("/dev/shm")) <= shm_before          # close() unlinked every segment
+
+
+def test_worker_regions_are_compacted_into_the_staging_buffer():
+    """The process back end's segment is 1.5x oversized and split evenly between the workers; the copy into the page-locked staging
+    buffer (and therefore the upload) moves only what the workers wrote (data/decode.py Packed.compact_into)."""
+    import grip_amd  # noqa: F401
+    from grip_amd.data.decode import Packed
+    r = np.random.RandomState(0)
+    src = r.randint(0, 256, size=4096).astype(np.uint8)
+    shapes = np.array([[2, 10], [3, 10], [1, 5], [4, 4]], dtype=np.int32)        # image bytes: 60, 90, 15, 48
+    offsets = np.array([0, 256, 2048, 2304], dtype=np.int64)                    # worker 0 owns [0, 2048), worker 1 [2048, 4096)
+    packed = Packed(offsets, shapes, 2304 + 256, regions=[(0, 512, 0, 2), (2048, 512, 2, 4)])
+    dst = np.zeros(1024, dtype=np.uint8)
+    out = packed.compact_into(src, dst)
+    assert out.used == 1024 and out.offsets.tolist() == [0, 256, 512, 768]
+    for i, (h, w) in enumerate(shapes):
+        n = int(h) * int(w) * 3
+        assert np.array_equal(dst[out.offsets[i]: out.offsets[i] + n], src[offsets[i]: offsets[i] + n])

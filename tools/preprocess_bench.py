@@ -77,5 +77,5 @@ from grip_amd.data.decode import usable_cpus  # noqa: E402
 print(f'usable cpus (affinity, cgroup quota): {usable_cpus()}')
 for pr in (8, 16, 24, 32):
     if pr <= 2 * usable_cpus():
-        print(f"pipelined (decode one chunk of {CHUNK} ahead), {pr:3d} decode processes: {pipelined(processes=pr):8.0f} img/s  (shared segment page-locked: {all(pre.__dict__['_procs']['pinned'])})")
+        print(f"pipelined (decode one chunk of {CHUNK} ahead), {pr:3d} decode processes: {pipelined(processes=pr):8.0f} img/s")
 pre.close()
