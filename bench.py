@@ -503,7 +503,7 @@ def secondary_block(loop, lib):
     return out
 
 
-def from_files_block(loop):
+def from_files_block(loop, n=1024, chunk=512, procs=None, slots=1):
     """SURVEY.md 8f-2 (the reference's data/dataset.py:56-89 + utils/clip_pseudolabels.py:31-33: PIL open + transform per image on
     the host): images/sec from JPEG FILES to embeddings -- parallel decode on the host (threads, and worker processes around a
     shared-memory segment), one upload + one batched preprocess launch pair per chunk, the f16 ViT-B/16 encode of chunk i running
@@ -517,7 +517,6 @@ def from_files_block(loop):
 
     from grip_amd.data.decode import default_processes, usable_cpus
     from grip_amd.preprocess import ClipPreprocess
-    n, chunk = 1024, 512
     d = tempfile.mkdtemp(prefix="grip_bench_files_")
     g = np.random.RandomState(0)
     paths = []
@@ -553,7 +552,7 @@ def from_files_block(loop):
                 one_pass(encode, **kw)
             return passes * n / (time.perf_counter() - t0)
 
-        procs = default_processes()
+        procs = default_processes() if procs is None else procs
         out = {"files": n, "chunk": chunk, "usable_cpus": usable_cpus(), "host_cpu_count": os.cpu_count(),
                "threads_8_decode_preprocess_encode": rate(True, workers=8, processes=0)}
         if procs > 0:
