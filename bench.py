@@ -46,7 +46,7 @@ PEAK_F16_TFLOPS = 2500.0 # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_16x16x4_f32), the exact mode's roof
 EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE", "EPI_LNFOLD_F16",
              "EPI_LNFOLD_GELU_F16", "EPI_BIAS_RESID_STATS"]
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 PEAK_CLOCK_MHZ = 2400.0  # the shader clock behind the 2.5 PFLOP/s figure
 
 
@@ -595,7 +595,7 @@ def main():
     ap.add_argument("--cpu-text-reps", type=int, default=6, help="how many of them time the full clip_model(image, text) call (the per-image text re-encode)")
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="wall-clock seconds the CPU baseline may take (it stops sampling when they are spent)")
     ap.add_argument("--cpu-full", action="store_true", help="time the literal R-mode loop on every sampled image (~6 s each)")
-    ap.add_argument("--lookahead", type=int, default=13,
+    ap.add_argument("--lookahead", type=int, default=51,
                     help="CoOp steps whose frozen image-tower forward is batched into one encode (steps.lookahead_image_features); 1 = encode inside every step")
     ap.add_argument("--graph", type=int, default=1, choices=(0, 1),
                     help="1: the CoOp step's forward + backward replayed from a HIP graph captured once (steps.GraphedCoopStep); 0: eager launches")
@@ -721,6 +721,9 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "Flowers102-shaped CoOp textual-prompt SSL pseudolabel+prompt-step loop, ViT-B/16 (BASELINE.json configs[1])",
                    "pseudolabel_mode": args.mode,
+                   "comparable_to_earlier_rounds": "rounds 1-2 timed the f16 lists (no index guarantee): compare their `value` with `f16_mode_loop.images_per_sec` "
+                                                   "of this line; `value` here is the identical mode (the default of utils.pseudolabel_top_k since round 3)"
+                                                   if args.mode == "identical" else "same path as rounds 1-2",
                    "index_guarantee": ("`value` itself carries it: every timed pass returns the lists of the fp32 (exact-mode) scan -- f16 towers screen the pool, "
                                        "the error-bounded scan marks the rows whose f16 probabilities cannot decide a comparison the lists depend on, "
                                        "the f32 towers re-encode those rows, until the scan certifies its lists (pseudolabels.refine_scan; equality with the "

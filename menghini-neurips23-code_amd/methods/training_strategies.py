@@ -239,7 +239,7 @@ class TrainingStrategy:
         """One epoch of the strategy's prompt step (the `_train_epoch` bodies of the reference, e.g. textual_prompt.py:63-159).
         Default: every full-sized batch replays the step's forward + backward from a HIP graph (steps.Graphed*Step; a batch of
         another shape -- the ragged last one -- runs the same kernels eagerly), the textual modality encodes the frozen image
-        tower `IMAGE_LOOKAHEAD` (13) batches at a time when its features are not cached, and loss / accuracy accumulate on the
+        tower `IMAGE_LOOKAHEAD` (51) batches at a time when its features are not cached, and loss / accuracy accumulate on the
         device: one host synchronisation per epoch instead of three per batch.  `GRAPH_STEPS: False` or gradient accumulation
         (ACCUMULATION_ITER > 1) take the eager per-batch path."""
         classes, ids, lut = self._class_space(only_seen)
@@ -261,7 +261,7 @@ class TrainingStrategy:
                 stream = ((self.frozen_image_features(img, names), label, w) for img, label, w, names in batches())
             else:           # every image is encoded every time it is used, a group of batches per frozen-tower forward
                 stream = steps.lookahead_image_features(self.clip_model, ((img, label, w) for img, label, w, _ in batches()),
-                                                        int(getattr(self.config, "IMAGE_LOOKAHEAD", 13)))
+                                                        int(getattr(self.config, "IMAGE_LOOKAHEAD", 51)))
         else:
             stream = ((img, label, w) for img, label, w, _ in batches())
         for x, label, w in stream:

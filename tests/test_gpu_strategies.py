@@ -260,3 +260,37 @@ def test_train_epoch_graph_replay_equals_eager_epoch(tmp_path, monkeypatch, cls_
     (s_g, p_g), (s_e, p_e) = out
     assert s_g == s_e, (s_g, s_e)
     assert all(torch.equal(a, b) for a, b in zip(p_g, p_e))
+
+
+@pytest.mark.parametrize("cls_name,paradigm", [("TextualFPL", "ssl"), ("VisualFPL", "ul"), ("MultimodalFPL", "trzsl")])
+def test_assign_pseudo_labels_default_mode_returns_the_fp32_lists(tmp_path, monkeypatch, cls_name, paradigm):
+    """The trained-prompt pseudolabel pass of GRIP (the nine assign_pseudo_labels) in the default `identical` mode: the lists are
+    those of the all-f32 computation with the SAME prompts (exact twin: f32 text tower with the trained textual prompt / mixer
+    output, f32 vision tower with the trained visual prompt, arg-max on the logits), whatever the f16 towers' own lists are."""
+    import grip_amd  # noqa: F401
+    from grip_amd import methods, pseudolabels as pl
+    from grip_amd.data import TensorPoolDataset
+    from grip_amd.methods.main import synthetic_pool
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("GRIP_PSEUDOLABEL_MODE", raising=False)
+    classes, files, images, names = synthetic_pool(5, 40, 64, 17)
+    l2i = {c: i for i, c in enumerate(classes)}
+    conf = _conf(MODEL="x", LEARNING_PARADIGM=paradigm, TEXT_PREFIX_SIZE=4, VISION_PREFIX_SIZE=4)
+    seen, unseen = (classes[:2], classes[2:]) if paradigm == "trzsl" else (classes, classes)
+    m = getattr(methods, cls_name)(conf, l2i, "", classes, seen, unseen, "cuda")
+    m.define_model(classes)
+    with torch.no_grad():
+        for p in m.model.parameters():
+            if p.requires_grad:
+                p.add_(torch.randn_like(p) * 0.05)
+    target = unseen if paradigm == "trzsl" else classes
+    twin = m.clip_model.exact_twin()
+    with torch.no_grad():
+        txt, vprompt = m.trained_text_features(target, twin)
+        emb = pl.encode_pool(twin.visual.tower, images.cuda(), chunk=32, prefix=vprompt)
+    want = pl.pseudolabel_from_features(emb, txt, m.scale(), list(files), [l2i[c] for c in target], 7, argmax_on="logits")
+    data = TensorPoolDataset(files, images.cuda(), labels=None, label_map=l2i)
+    pl.LAST_REFINE_STATS = None
+    out = m.assign_pseudo_labels(7, data)
+    assert (out.filepaths, out.labels) == want and pl.LAST_REFINE_STATS is not None and len(want[0]) > 7
+    assert pl.LAST_REFINE_STATS["rows_refined"] < len(files)

@@ -1,5 +1,5 @@
 """Fold the per-kernel PMC CSVs written by tools/collect_profiles.sh into profiles/r<NN>_traffic.json (what bench.py
-reports as roofline.traffic / roofline.mfma_util).  Usage: python tools/pmc_summary.py gpurun_out/prof_<tag> <tag> [round=02] [traffic=1]"""
+reports as roofline.traffic / roofline.mfma_util).  Usage: python tools/pmc_summary.py gpurun_out/prof_<tag> <tag> [round=03] [traffic=1]"""
 import csv
 import json
 import os
@@ -7,7 +7,7 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-RND = sys.argv[3] if len(sys.argv) > 3 else "02"
+RND = sys.argv[3] if len(sys.argv) > 3 else "03"
 WRITE_TRAFFIC = (sys.argv[4] if len(sys.argv) > 4 else "1") == "1"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_XCD, N_SIMD = 8, 1024
@@ -36,8 +36,8 @@ for k, c in per.items():
     kernels[k] = e
 out = {
     "_how": "tools/collect_profiles.sh: three separate rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | "
-            "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES) of `python bench.py --no-cpu-baseline --pool 13200 --steps 1 "
-            "--warmup 0` (default encode chunk 1320: ten full chunks); per-kernel averages over launches. FETCH_SIZE (KiB) is doubled per "
+            "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES) of `python bench.py --no-cpu-baseline --no-secondary --no-exact --graph 0 --lookahead 1 --pool 13200 --steps 1 "
+            "--warmup 0` (default encode chunk 1320: ten full chunks; default identical mode: the exact re-encodes of the marked rows are in the pass too); per-kernel averages over launches. FETCH_SIZE (KiB) is doubled per "
             "MI355X_MICROARCH.md (gfx950 tallies a wide coalesced read stream at half its bytes); mfma_util = "
             "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), i.e. against the ACTUAL shader clock "
             "(~2.05 GHz under this load, not the 2.4 GHz behind the 2.5 PF/s peak)",
