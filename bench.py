@@ -503,7 +503,7 @@ def secondary_block(loop, lib):
     return out
 
 
-def from_files_block(loop, n=1024, chunk=512, procs=None, slots=1):
+def from_files_block(loop, n=1536, chunk=384, procs=None, slots=1):
     """SURVEY.md 8f-2 (the reference's data/dataset.py:56-89 + utils/clip_pseudolabels.py:31-33: PIL open + transform per image on
     the host): images/sec from JPEG FILES to embeddings -- parallel decode on the host (threads, and worker processes around a
     shared-memory segment), one upload + one batched preprocess launch pair per chunk, the f16 ViT-B/16 encode of chunk i running
