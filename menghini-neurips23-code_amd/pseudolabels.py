@@ -134,6 +134,10 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
     shard; one small all-gather per round).  Bit-for-bit the lists of the exact mode (tests/test_gpu_identical.py)."""
     global LAST_REFINE_STATS
     n = len(paths)
+    if n == 0:
+        LAST_REFINE_STATS = {"rows": 0, "rows_refined": 0, "rounds": 0, "scans": 0, "calibration_rows": 0, "refined_per_round": [], "eps": 0.0, "max_deviation": 0.0,
+                             "safety": REFINE_SAFETY, "rows_refined_this_rank": 0}
+        return [], []
     emb = emb16 if emb16 is not None else encode_pool(visual16, images, chunk=chunk, prefix=prefix)
     dev = emb.device
     _, probs, am_l, am_p = engine.cosine_head(emb, txt_exact, scale)

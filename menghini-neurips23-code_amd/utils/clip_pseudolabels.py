@@ -26,8 +26,10 @@ def _pool_images(dataset, transform, device):
     native_pre = hasattr(transform, "decode_chunk")
     workers = int(os.environ.get("GRIP_DECODE_WORKERS", str(min(32, os.cpu_count() or 8))))
     from ..data.decode import default_processes
-    procs = os.environ.get("GRIP_DECODE_PROCS", "0")        # decode processes are opt-in (a number, or "auto" = one per usable CPU)
-    procs = default_processes() if procs == "auto" else int(procs)
+    # decode processes: a number, or "auto" (default) = 1.5 per usable CPU for pools of >= 512 files (the thread back end for smaller
+    # pools: starting two dozen interpreters costs more than decoding a few hundred images); "0" = threads only
+    procs = os.environ.get("GRIP_DECODE_PROCS", "auto")
+    procs = (default_processes() if len(paths) >= 512 else 0) if procs == "auto" else int(procs)
 
     class _Lazy:
         n = len(paths)
@@ -65,7 +67,7 @@ def _pool_images(dataset, transform, device):
 
 
 def compute_pseudo_labels(k, template, dataset, classnames, transform, clip_model, label_to_idx, device, filename,
-                          chunk=220):
+                          chunk=880):
     prompts = [f"{template}{' '.join(i.split('_'))}" for i in classnames]     # reference :24 (literal "{}" kept)
     text = clip.tokenize(prompts).to(device)
     class_labels = [label_to_idx[c] for c in classnames]
