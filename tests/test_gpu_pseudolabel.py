@@ -76,14 +76,16 @@ def test_pseudolabel_top_k_matches_reference_algorithm(tmp_path, monkeypatch, k)
     # (2) the probabilities agree with the fp32 oracle to f16-operand accuracy.  Softmax of 100 x cosine: an embedding error of
     # 1e-3 relative L2 (the measured parity margin) moves a logit by up to ~0.1 and a probability by up to ~0.025; the worst
     # seen over kernel revisions is 5.1e-3 on this random-init model.  The binding criteria are (1) and (3).
-    assert np.abs(g_probs.cpu().numpy() - o_probs).max() <= 1e-2
+    assert np.abs(g_probs.cpu().numpy() - o_probs).max() <= 5e-3      # measured 2.4e-3 (r03)
     # (3) end to end against the oracle's own lists.  The scan compares near-tied probabilities with strict '<', so a
     # 4th-digit difference (f16 operands and residual stream vs the fp32 oracle) may swap a boundary item: the lists must
     # agree on at least 90 % of the (image, label) pairs, and the arg-max-only branch on 99 % of the images.
     got_pairs, want_pairs = set(zip(ds.filepaths, ds.labels)), set(zip(want_fp, want_lab))
     overlap = len(got_pairs & want_pairs) / len(want_pairs)
     print(f"k={k}: f16 lists overlap the fp32 oracle's {overlap:.4f}; max |dp| {np.abs(g_probs.cpu().numpy() - o_probs).max():.2e}")
-    assert overlap >= (0.99 if k == 10000000 else 0.90), overlap
+    # measured (r03): k = 3: 20 of 21 pairs (0.952), k = 16: 1.000, label-everything: 1.000.  This is the f16 MODE (no index guarantee); the
+    # default mode returns the fp32 lists themselves (tests/test_gpu_identical.py)
+    assert overlap >= {3: 0.95, 16: 0.98}.get(k, 0.995), overlap
     want_fp, want_lab = ds.filepaths, ds.labels
     # cache: file name and schema of utils/clip_pseudolabels.py:134 / :114-115
     fn = f"pseudolabels/EuroSAT_ViT-B32_ul_visual_fpl_{k}_pseudolabels_split_500.pickle"
