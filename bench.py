@@ -780,6 +780,10 @@ def main():
         if not args.no_exact:
             clock_marker("exact")
             out["exact"] = exact_block(loop, lib)
+            if args.mode == "identical" and not out["exact"]["timed_loop_lists_identical_to_exact"]:
+                # never quote a guarantee the run itself contradicts
+                out["config"]["index_guarantee"] = "VIOLATED in this run: the timed loop's lists differ from the exact mode's on this pool (see `exact`)"
+                print("bench.py: identical-mode lists DIFFER from the exact mode's lists on this pool", file=sys.stderr, flush=True)
         if not args.no_secondary:
             del loop.pool
             loop.pool = synth_pool(64, loop.d.image_resolution, device, 99)
