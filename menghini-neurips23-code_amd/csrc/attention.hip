@@ -30,6 +30,14 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 
 // One 16-row query tile against the K / V^T of one (image, head) held in LDS: scores, softmax, P.V, store.
 // qf = the tile's two Q fragments (unscaled); orow = the output row pointer of this lane's query (+ head offset).
+// s_setprio(1) around phases of a query tile (r03).  Bit 0: the score MFMAs, bit 1: the exponentials, bit 2: P.V.  Measured (one box, two
+// runs each, tools/attn_one.py; us per launch at 1320 x 12 x S = 197 (persistent kernel) / 128 x 16 x S = 577 (plain kernel)): off 416 / 380;
+// 1: 412 / 352; 2: 443 / 362; 4: 444 / 361; 5: 439 / 359; 7: 440 / 361.  A wave that wins the issue arbitration while it issues its 2 x 14 (36 at
+// S = 577) score MFMAs reaches its exponentials sooner and leaves the matrix pipe to the SIMD's other waves; prioritising the VALU or P.V phases
+// only reorders waves that are all in the same phase.  Default 1: -7 % at S = 577 (ViT-L/14@336px), -1 % at S = 197.
+#ifndef GRIP_ATTN_PRIO
+#define GRIP_ATTN_PRIO 1
+#endif
 template <int KVC, bool CAUSAL>
 __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, half8 (&qf)[2], int qrow, int S, half_t* orow, int lane, bool do_store = true) {
     constexpr float LOG2E = 1.4426950408889634f;
@@ -38,6 +46,7 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
     for (int kk = 0; kk < 2; ++kk) qf[kk] *= (half_t)0.125f;  // 1/sqrt(64), exact in f16
     f32x4 sc[2 * KVC];
     float m = -INFINITY;
+    if (GRIP_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
     // The launcher guarantees (KVC-1)*32 < S <= KVC*32: every tile before the last 32-key chunk is full, so
     // only the last two tiles (and causal rows) pay for the mask; the code stays one straight-line block.
 #pragma unroll
@@ -58,13 +67,16 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
         m = max3(max3(m, acc[0], acc[1]), acc[2], acc[3]);
         sc[t] = acc;
     }
+    if (GRIP_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(0);
     m = fmaxf(m, __shfl_xor(m, 16));
     m = fmaxf(m, __shfl_xor(m, 32));
     const float m2 = m * LOG2E;
+    if (GRIP_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < 2 * KVC; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -m2));   // exp(s - m)
+    if (GRIP_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(0);
 
     // The row sums come out of the matrix pipe: a fifth accumulator takes an all-ones A operand, so every row of it is
     // sum_k P[q][k] for the lane's own query (56 v_add and two cross-lane steps per tile less on the VALU, which is the
@@ -74,6 +86,7 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
     f32x4 o[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) o[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (GRIP_ATTN_PRIO & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int c = 0; c < KVC; ++c) {
         const half8 pf = {(half_t)sc[2 * c][0], (half_t)sc[2 * c][1], (half_t)sc[2 * c][2], (half_t)sc[2 * c][3],
@@ -85,6 +98,7 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
         }
         osum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf, osum, 0, 0, 0);
     }
+    if (GRIP_ATTN_PRIO & 4) __builtin_amdgcn_s_setprio(0);
     if (qrow < S && do_store) {
         const float inv = __builtin_amdgcn_rcpf(osum[0]);
         half_t* op = orow + lg * 16;

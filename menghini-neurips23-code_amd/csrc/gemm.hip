@@ -29,6 +29,15 @@
 #ifndef GRIP_RD0
 #define GRIP_RD0 4
 #endif
+// s_setprio around the MFMA sub-steps of the persistent GEMM (r03).  Bit 0: sub-step 0, bit 1: sub-step 1, for every epilogue (developer
+// A/B); 4 (default): sub-step 1 of the LayerNorm-folded instantiations only.  Measured on one box, f16 bench loop, two runs each (TF/s of
+// QKV / c_fc / residual): off 1 097 / 997 / 1 045; sub-step 0: 1 031 / 949 / 1 034; sub-step 1: 1 119 / 1 006 / 1 031; both: 1 054 / 958 / 1 027.
+// While a wave is in the sub-step that also issues the stage's DMA pieces and the next fragment reads, winning the issue arbitration
+// against the SIMD's other wave shortens that burst for the wide-output GEMMs (+2.0 % QKV, +0.9 % c_fc); the narrow residual GEMMs lose
+// 1.3 % with it (their leading tiles wait on memory either way: the other wave's MFMAs are what fills that wait), so they stay without.
+#ifndef GRIP_SETPRIO
+#define GRIP_SETPRIO 4
+#endif
 #ifndef GRIP_KROT
 #define GRIP_KROT 1
 #endif
@@ -1213,11 +1222,16 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = (par + kt) & 1;
             load_frags(1, buf, 1);
+            constexpr bool PRIO0 = (GRIP_SETPRIO & 1) && GRIP_SETPRIO < 4;
+            constexpr bool PRIO1 = ((GRIP_SETPRIO & 2) && GRIP_SETPRIO < 4) || (GRIP_SETPRIO == 4 && (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16));
+            if constexpr (PRIO0) __builtin_amdgcn_s_setprio(1);
             mfma_set(0);
             spread();
+            if constexpr (PRIO0) __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
+            if constexpr (PRIO1) __builtin_amdgcn_s_setprio(1);
             if constexpr (SD) {
                 // Sub-step 1 as ONE basic block, so that the scheduler can place the stage's 8 DMA pieces and the 12 fragment reads
                 // BETWEEN the 32 MFMAs (as three separate blocks -- the branchy form below -- they are a DMA burst, then a read
@@ -1252,6 +1266,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
                 mfma_set(1);
                 spread();
             }
+            if constexpr (PRIO1) __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (EMODE == 4)
             epilogue_rows8h<EPI, true>(g, acc, (half_t*)slab, m0 + wr * 128, n0 + wc * 64, lane, pre);
