@@ -38,6 +38,11 @@
 #ifndef GRIP_SETPRIO
 #define GRIP_SETPRIO 4
 #endif
+// Developer experiment (r03): s_setprio(1) over the K step of the small-M kernels (gemm_f16_kernel, gemm_ring_kernel): no effect on the
+// prompt steps (CoOp 2.62 / VPT 3.46 / UPT 4.01 ms eager either way), off
+#ifndef GRIP_SMALL_PRIO
+#define GRIP_SMALL_PRIO 0
+#endif
 #ifndef GRIP_KROT
 #define GRIP_KROT 1
 #endif
@@ -592,6 +597,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
         __syncthreads();  // tile kt visible to every wave, tile kt-1 fully read
         if (kt + 1 < nk) stage(buf ^ 1, kt0 + ks(kt + 1));
         const half_t* st = lds + buf * STAGE;
+        if (GRIP_SMALL_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             half8 af[WMF], bf[4];
@@ -605,6 +611,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
+        if (GRIP_SMALL_PRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     __syncthreads();   // every wave is done with the stage buffers: reuse them as epilogue slabs
@@ -694,6 +701,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
         __builtin_amdgcn_s_barrier();             // tile kt landed for every wave; the slot of tile kt-1 has been read by every wave
         if (kt + NST - 1 < nk) stage(nbuf, kt0 + ks(kt + NST - 1));
         const half_t* st = lds2 + buf * STAGE;
+        if (GRIP_SMALL_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             half8 af[WMF], bf[4];
@@ -707,6 +715,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
+        if (GRIP_SMALL_PRIO) __builtin_amdgcn_s_setprio(0);
         buf = buf + 1 == NST ? 0 : buf + 1;
         nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
     }

@@ -15,6 +15,12 @@
 
 #include "common.h"
 
+// s_setprio(1) over a K step's fragment reads + MFMAs (1) or its MFMAs only (2); 0 = off.  Two workgroups share a CU (two waves per SIMD);
+// measured (r03, exact ViT-B/16 encode, same box, two runs each): off 3 254 / 3 241 img/s, 1: 3 324 / 3 322, 2: 3 206 / 3 212; results bit-identical.
+#ifndef GRIP_F32_PRIO
+#define GRIP_F32_PRIO 1
+#endif
+
 #define BKF 32                       // floats per LDS row
 #define STAGE_F ((128 + 128) * BKF)  // floats per stage = 32 KiB
 
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
         __syncthreads();   // stage kt visible to every wave, stage kt-1 fully read
         if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
         const float* st = lds + buf * STAGE_F;
+        if (GRIP_F32_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f32x4 af[4], bf[4];
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
             for (int i = 0; i < 4; ++i) af[i] = *(const f32x4*)(st + a_off[kk] + i * 16 * BKF);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = *(const f32x4*)(st + b_off[kk] + j * 16 * BKF);
+            if (GRIP_F32_PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -104,7 +112,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+            if (GRIP_F32_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         }
+        if (GRIP_F32_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
 
     // epilogue: lane (frow, fgrp) holds columns col0 + j*16 + fgrp*4 .. +3 of row row0 + i*16 + frow
