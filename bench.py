@@ -606,7 +606,7 @@ def main():
                     help="strong scaling: --pool is the TOTAL number of images, split evenly over the ranks (default: weak, --pool images per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the fp32 comparison-mode block")
-    ap.add_argument("--exact-chunk", type=int, default=440, help="images per launch of the f32 towers (refinement rounds and the exact block): 220 -> 3 182, 440 -> 3 244, 880 -> 3 282 img/s; rows are bit-identical under any chunking")
+    ap.add_argument("--exact-chunk", type=int, default=880, help="images per launch of the f32 towers (refinement rounds and the exact block): 220 -> 3 182, 440 -> 3 244, 880 -> 3 282 img/s; rows are bit-identical under any chunking")
     ap.add_argument("--no-secondary", action="store_true", help="skip the VPT / UPT / ViT-L/14@336px block")
     args = ap.parse_args()
 

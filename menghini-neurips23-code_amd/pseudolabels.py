@@ -125,7 +125,7 @@ def take_images(images, idx):
 
 
 @torch.no_grad()
-def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_labels, k, chunk=880, exact_chunk=440, prefix=None,
+def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_labels, k, chunk=880, exact_chunk=880, prefix=None,
                     argmax_on="probs", streams=2, emb16=None):
     """(filepaths, labels) of the reference's fp32 pseudolabel scan (utils/clip_pseudolabels.py:24-112) at close to the f16
     towers' throughput: the whole pool goes through the f16 vision tower `visual16` (sharded over ranks, one all-gather), the
