@@ -16,6 +16,11 @@
 
 #include "common.h"
 
+// Developer experiment (r03): s_setprio(1) around the score MFMAs of phase 1 (bit 0), the dQ MFMAs (bit 1), phase 2's S / dP MFMAs (bit 2), its dK / dV MFMAs (bit 3)
+#ifndef GRIP_ATTNB_PRIO
+#define GRIP_ATTNB_PRIO 0
+#endif
+
 template <int KVC, bool CAUSAL, int NWB>
 __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ o_saved,
                                                        const half_t* __restrict__ d_out, half_t* __restrict__ dqkv, int S, int H,
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
 
         f32x4 sc[2 * KVC];
         float m = -INFINITY;
+        if (GRIP_ATTNB_PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 2 * KVC; ++t) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
             }
             sc[t] = acc;
         }
+        if (GRIP_ATTNB_PRIO & 1) __builtin_amdgcn_s_setprio(0);
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         float sum = 0.f;
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
         f32x4 dq[4];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) dq[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (GRIP_ATTNB_PRIO & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int c = 0; c < KVC; ++c) {
             const half8 sf = {(half_t)sc[2 * c][0], (half_t)sc[2 * c][1], (half_t)sc[2 * c][2], (half_t)sc[2 * c][3],
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                 dq[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, sf, dq[nf], 0, 0, 0);
             }
         }
+        if (GRIP_ATTNB_PRIO & 2) __builtin_amdgcn_s_setprio(0);
         if (qrow < S && qrow >= q_min) {
             half_t* op = dbase + qg * ld + lg * 4;
 #pragma unroll
@@ -183,24 +192,37 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) { dk[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         const int c_begin = CAUSAL ? (kt * 16) / 32 : 0;   // queries before the key tile see none of its keys
+        // A operands of the recomputed S and dP: query rows of Q and dO straight from HBM / L2 (row = q0 + li); the LDS holds the
+        // transposed images only.  The rows of 16-query step `it + 1` are requested before step `it` is computed (r03: the loads of a
+        // step used to be issued at its top, a full L2 round trip exposed per step and wave -- 14 steps per key tile at S = 213).
+        auto load_rows = [&](int it, half8 (&qa_f)[2], half8 (&do_f)[2]) {
+            const int qa = (it * 16 + li) < S ? (it * 16 + li) : S - 1;
+            const size_t qag = R(qa);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                qa_f[kk] = *(const half8*)(base + qag * ld + (kk * 4 + lg) * 8);
+                do_f[kk] = *(const half8*)(dobase + qag * D + (kk * 4 + lg) * 8);
+            }
+        };
+        half8 q_nx[2], do_nx[2];
+        load_rows(2 * c_begin, q_nx, do_nx);
 #pragma unroll 1
         for (int c = c_begin; c < KVC; ++c) {     // not unrolled: KVC copies of this body cost > 256 VGPRs
             half8 pf, sf;
 #pragma unroll
             for (int half_i = 0; half_i < 2; ++half_i) {
                 const int q0 = c * 32 + half_i * 16;
-                // A operands: query rows straight from HBM (row = q0 + li)
-                const int qa = (q0 + li) < S ? (q0 + li) : S - 1;
-                const size_t qag = R(qa);
+                half8 qa_f[2] = {q_nx[0], q_nx[1]}, do_f[2] = {do_nx[0], do_nx[1]};
+                if (2 * c + half_i + 1 < 2 * KVC) load_rows(2 * c + half_i + 1, q_nx, do_nx);
                 f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+                if (GRIP_ATTNB_PRIO & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    half8 qa_f = *(const half8*)(base + qag * ld + (kk * 4 + lg) * 8);
-                    qa_f *= (half_t)0.125f;
-                    const half8 do_f = *(const half8*)(dobase + qag * D + (kk * 4 + lg) * 8);
-                    s_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa_f, kf[kk], s_acc, 0, 0, 0);   // S[q][kv]
-                    p_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(do_f, vf[kk], p_acc, 0, 0, 0);   // dP[q][kv]
+                    qa_f[kk] *= (half_t)0.125f;
+                    s_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa_f[kk], kf[kk], s_acc, 0, 0, 0);   // S[q][kv]
+                    p_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(do_f[kk], vf[kk], p_acc, 0, 0, 0);   // dP[q][kv]
                 }
+                if (GRIP_ATTNB_PRIO & 4) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + lg * 4 + r;
@@ -213,6 +235,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                     sf[half_i * 4 + r] = (half_t)ds;
                 }
             }
+            if (GRIP_ATTNB_PRIO & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
                 const half8 dof = *(const half8*)(T1 + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
@@ -220,6 +243,7 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
                 const half8 qtf = *(const half8*)(T0 + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
                 dk[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, sf, dk[nf], 0, 0, 0);   // dK^T[dh][kv]
             }
+            if (GRIP_ATTNB_PRIO & 8) __builtin_amdgcn_s_setprio(0);
         }
         if (kvrow < Ps) {
             // a shared key: this sequence's share goes to kv_part [b][key][dK | dV][D] in f32; attn_shared_kv_reduce adds the
