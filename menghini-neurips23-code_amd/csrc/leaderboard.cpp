@@ -260,7 +260,7 @@ struct BoundedScan {
             const int js = pred[i];
             const float eps = rel_eps[i];
             GRIP_REQUIRE(js >= 0 && js < c, "bounded leaderboard: pred[%lld] = %d out of range", (long long)i, js);
-            GRIP_REQUIRE(eps >= 0.f && eps < 0.5f, "bounded leaderboard: rel_eps[%lld] = %g out of range", (long long)i, (double)eps);
+            GRIP_REQUIRE(eps >= 0.f && eps < 1e6f, "bounded leaderboard: rel_eps[%lld] = %g out of range", (long long)i, (double)eps);    // (eps >= 1: the lower bound is <= 0, i.e. "could be anything below")
             const BEntry x = make_entry(p[js], eps, path_rank[i], (int32_t)i);
             const double up = 1.0 + (double)eps;
             cand.clear();                                                   // (A)

@@ -45,6 +45,18 @@ def _refine(p32, a32, p16, a16, paths, k, **kw):
     return ([paths[i] for i in img], [int(j) for j in cls]), st
 
 
+def test_large_deviations_only_cost_more_refinement():
+    """Screening probabilities that are off by tens of percent (a bound near or above 1: the lower end of an interval reaches 0) must
+    still end in the exact lists -- with most rows re-encoded."""
+    from oracle import cbind
+    r = np.random.RandomState(4)
+    p32, a32, _, _, paths = _pool(1500, 12, 0.4, 0.0, 21)
+    p16 = (p32.astype(np.float64) * np.exp(r.randn(*p32.shape) * 0.35)).astype(np.float32)
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(12)), 5)
+    got, st = _refine(p32, a32, p16, p16.argmax(1).astype(np.int32), paths, 5)
+    assert got == want and st["eps"] > 0.5 and st["rows_refined"] > 500
+
+
 CASES = [
     # n, c, k, spread, sigma, quantise, dup_paths, dominant
     (1, 3, 2, 1.0, 1e-3, 0, False, False),
