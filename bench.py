@@ -503,6 +503,44 @@ def secondary_block(loop, lib):
     return out
 
 
+def structured_pool_block(loop):
+    """The identical-mode pass on a pool with class structure (per-image colour cast + low-frequency ramp on top of noise, the recipe of
+    grip_amd.data.synthetic generated on the device): the timed pool is i.i.d. noise, on which the random-init tower gives every image the
+    same arg-max -- the hardest case for the screen (every image spills to every class).  Reported: rows re-encoded, rounds, pass rate."""
+    a = loop.args
+    dev = loop.device
+    n = a.pool
+    g = torch.Generator(device=dev).manual_seed(4242)
+    pool = torch.empty(n, 3, loop.d.image_resolution, loop.d.image_resolution, dtype=torch.float32, device=dev)
+    ramp = torch.linspace(-1.0, 1.0, loop.d.image_resolution, device=dev).view(1, 1, 1, -1)
+    for lo in range(0, n, 2048):
+        hi = min(lo + 2048, n)
+        x = torch.empty(hi - lo, 3, loop.d.image_resolution, loop.d.image_resolution, device=dev).normal_(generator=g)
+        mu = torch.empty(hi - lo, 3, 1, 1, device=dev).normal_(generator=g) * 2.0
+        r = torch.empty(hi - lo, 3, 1, 1, device=dev).normal_(generator=g)
+        pool[lo:hi] = x * 0.5 + mu + ramp * r
+    keep_pool, keep_stats, keep_stage = loop.pool, loop.refine_stats, dict(loop.stage)
+    loop.pool = pool
+    try:
+        loop.identical_pass(a.streams)          # warm-up of nothing new; first pass on this pool
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img, cls = loop.identical_pass(a.streams)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rs = loop.refine_stats
+        pred_hist = np.bincount(cls, minlength=a.classes)
+        return {"pool_images": n, "identical_images_per_sec": n / dt, "rows_reencoded_exactly": rs["rows_refined"], "fraction": rs["rows_refined"] / n,
+                "rounds": rs["rounds"], "rows_per_round": rs["refined_per_round"], "relative_bound": rs["eps"], "pairs": int(len(img)),
+                "classes_with_a_full_board": int((pred_hist >= a.k).sum()),
+                "note": "same loop, same towers, structured synthetic pool (seeded on the device; not the fixtures' CPU generator)"}
+    finally:
+        loop.pool, loop.refine_stats = keep_pool, keep_stats
+        loop.stage.update(keep_stage)
+        del pool
+        torch.cuda.empty_cache()
+
+
 def from_files_block(loop, n=1536, chunk=384, procs=None, slots=1):
     """SURVEY.md 8f-2 (the reference's data/dataset.py:56-89 + utils/clip_pseudolabels.py:31-33: PIL open + transform per image on
     the host): images/sec from JPEG FILES to embeddings -- parallel decode on the host (threads, and worker processes around a
@@ -784,12 +822,20 @@ def main():
                 # never quote a guarantee the run itself contradicts
                 out["config"]["index_guarantee"] = "VIOLATED in this run: the timed loop's lists differ from the exact mode's on this pool (see `exact`)"
                 print("bench.py: identical-mode lists DIFFER from the exact mode's lists on this pool", file=sys.stderr, flush=True)
+        structured = None
+        if not args.no_secondary and args.mode == "identical":
+            try:
+                structured = structured_pool_block(loop)
+            except Exception as e:
+                structured = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_secondary:
             del loop.pool
             loop.pool = synth_pool(64, loop.d.image_resolution, device, 99)
             torch.cuda.empty_cache()
             clock_marker("secondary")
             out["secondary"] = secondary_block(loop, lib)
+            if structured is not None:
+                out["secondary"]["identical_on_structured_pool"] = structured
             try:
                 out["secondary"]["from_files"] = from_files_block(loop)
             except Exception as e:      # the input pipeline is a NEXT row: its failure must not take the bench line down
