@@ -106,7 +106,10 @@ extern "C" int grip_leaderboard_scan(const float* probs, const int32_t* pred, co
 //  (C) the own-class decision of every image (:73-76 -> spill or not, :83): from the first overflow on a board is the sorted top-k
 //      of everything it was offered since, so `board[-1].score` is the k-th largest TRUE value among those offers, which lies
 //      between the k-th largest lower bound T_lo and the k-th largest upper bound T_hi of the offers.  Accept is certain when
-//      T_hi < lo(x), reject when T_lo >= hi(x); otherwise x and the un-refined offers whose intervals meet x's are marked.
+//      T_hi < lo(x), reject when T_lo >= hi(x); otherwise x and the un-refined offers whose intervals meet x's are marked -- unless
+//      every offer the spill would make is certainly irrelevant (below a sorted board's T_lo): then both outcomes leave the same
+//      state (no other board sees the image, its own board was offered it either way) and nothing is marked; and when only some of
+//      them could matter (and every board is sorted), they become CONDITIONAL offers that are checked against the final boards.
 //  (D) the FINAL content and order of every board (:103-109).  Offers from other classes' spills (:83-101) need no certain
 //      decision at the time they are made: an offer whose upper bound is below T_lo can never be among the k largest (k
 //      offers are certainly above it) and is dropped; the others are recorded, and at the end the nominal board B must be
@@ -164,13 +167,16 @@ struct BBoard {
     bool sorted = false;
     TopK lo, hi;                // bounds of the true k-th largest offer since the first overflow
     std::vector<BEntry> rec;    // offers since the first overflow that were not certainly irrelevant when they arrived
+    std::vector<BEntry> cond;   // offers that are made only if an undecidable own-class decision of their image went "reject" (see (C))
     size_t prune_at = 0;
 };
 struct Marks {
     uint8_t* flag;
     int64_t count = 0;
+    int cat = 0;                // what the scan is deciding right now (GRIP_SCAN_DEBUG prints the first-mark tally per category)
+    int64_t by_cat[6] = {0, 0, 0, 0, 0, 0};
     inline void mark(const BEntry& x) {
-        if (x.eps != 0.f && !flag[x.img]) { flag[x.img] = 1; ++count; }
+        if (x.eps != 0.f && !flag[x.img]) { flag[x.img] = 1; ++count; ++by_cat[cat]; }
     }
 };
 
@@ -276,8 +282,10 @@ struct BoundedScan {
                 bool all_reject = certainly_rejects(js, x);
                 for (size_t q = 0; all_reject && q < cand.size(); ++q)
                     all_reject = certainly_rejects(cand[q], make_entry(p[cand[q]], eps, x.rank, x.img));
+                mk.cat = 1;
                 if (!all_reject) mk.mark(x);
             }
+            mk.cat = 2;
             bool spill;
             if ((int64_t)own.e.size() < kk) {
                 spill = false;
@@ -285,15 +293,44 @@ struct BoundedScan {
                 spill = !(own.e.back().score < x.score);
                 const bool sure_accept = own.hi.kth() < x.lo, sure_reject = t_lo[(size_t)js] >= x.hi;
                 if (!sure_accept && !sure_reject) {
-                    mk.mark(x);
-                    for (const BEntry& y : own.rec)
-                        if (y.eps != 0.f && y.lo <= x.hi && y.hi >= x.lo) mk.mark(y);
+                    // Undecidable -- but if every offer the spill would make is certainly irrelevant (below the certain threshold of a
+                    // sorted board), the two outcomes leave the same state: no other board sees the image either way, and its own board
+                    // was OFFERED it either way (the k-th largest offer, hence every later threshold, counts it in both cases; whether it
+                    // is in the final board is certified at the end like any recorded offer).
+                    bool spill_irrelevant = true;
+                    for (int j = 0; spill_irrelevant && j < c; ++j)
+                        if (j != js) spill_irrelevant = boards[(size_t)j].sorted && (double)p[j] * up < t_lo[(size_t)j];
+                    bool can_defer = eps != 0.f;
+                    for (int j = 0; can_defer && !spill_irrelevant && j < c; ++j)
+                        if (j != js) can_defer = boards[(size_t)j].sorted;          // an unsorted board loses a rejected offer for good: no deferral
+                    if (spill_irrelevant) {
+                        spill = false;          // record it with its own board (nominal_insert keeps or rejects it nominally)
+                    } else if (can_defer) {
+                        // The spill's offers become CONDITIONAL: they are made only in the world where the own class rejected the image.
+                        // They stay out of every board and out of T_lo (a k-th largest lower bound over fewer offers is still a lower
+                        // bound), count towards T_hi (an upper bound over more offers is still an upper bound), and at the end each must
+                        // be certainly below its board's last element -- then the final boards are the same in both worlds; otherwise the
+                        // image is marked (it is un-refined: eps != 0).
+                        spill = false;
+                        for (int j = 0; j < c; ++j) {
+                            if (j == js || (double)p[j] * up < t_lo[(size_t)j]) continue;
+                            BBoard& b = boards[(size_t)j];
+                            const BEntry y = make_entry(p[j], eps, x.rank, x.img);
+                            b.cond.push_back(y);
+                            b.hi.push(y.hi);
+                        }
+                    } else {
+                        mk.mark(x);
+                        for (const BEntry& y : own.rec)
+                            if (y.eps != 0.f && y.lo <= x.hi && y.hi >= x.lo) mk.mark(y);
+                    }
                 }
             } else {
                 const int lt = certainly_less(own.e.back(), x);
                 if (lt < 0) { mk.mark(own.e.back()); mk.mark(x); }
                 spill = !(lt >= 0 ? lt == 1 : own.e.back().score < x.score);
             }
+            mk.cat = 3;
             if (!spill) {
                 offer(js, x);
             } else {
@@ -305,6 +342,7 @@ struct BoundedScan {
             }
         }
         if (!label_all && !strict) {                                        // (D): certify the final boards
+            mk.cat = 4;
             std::vector<uint8_t> in_board((size_t)std::max<int64_t>(n, 1), 0);
             for (int j = 0; j < c; ++j) {
                 BBoard& b = boards[(size_t)j];
@@ -323,6 +361,8 @@ struct BoundedScan {
                         if (last.eps == 0.f || y.hi >= (double)last.score) mk.mark(y);   // the rest waits until `last` is final
                     }
                 }
+                for (const BEntry& y : b.cond)
+                    if (!(y.hi < last.lo)) { mk.mark(y); if (y.hi < (double)last.score) mk.mark(last); }
                 for (const BEntry& y : b.e) in_board[(size_t)y.img] = 0;
             }
         }
@@ -339,6 +379,9 @@ struct BoundedScan {
         }
         *out_count = m;
         *n_ambiguous = mk.count;
+        if (getenv("GRIP_SCAN_DEBUG"))
+            fprintf(stderr, "bounded scan marks: arg-max %lld, own-class decision %lld, unsorted-regime offers %lld, final boards %lld (strict %d)\n",
+                    (long long)mk.by_cat[1], (long long)mk.by_cat[2], (long long)mk.by_cat[3], (long long)mk.by_cat[4], (int)strict);
         return GRIP_OK;
     }
 };

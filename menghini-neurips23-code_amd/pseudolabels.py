@@ -49,13 +49,16 @@ REFINE_CALIB_ROWS = 256     # rows re-encoded exactly up front to measure the f1
 REFINE_SAFETY = 2.0         # bound = safety x the largest deviation seen on any row re-encoded so far (it only ever grows)
 
 
+REFINE_ESCALATE_AFTER = 8   # rounds after which whatever is still un-refined is re-encoded in one go (pathological pools only, see refine_scan)
+
+
 def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safety=REFINE_SAFETY, max_rounds=64):
     """Leaderboard lists of the reference's fp32 scan from probabilities of the f16 towers (utils/clip_pseudolabels.py:38-112).
 
     `probs` [N, C] f32 / `pred` [N] come from the f16 image tower (modified in place); `exact_rows(idx)` returns the exact
     (f32-tower) probabilities and arg-max of the rows `idx` (ascending int64 array).  The f16 rows are trusted only up to a relative
     bound eps = safety x (largest |p16 / p32 - 1| over every row re-encoded so far, starting with `calib` rows -- at most 1/16 of
-    the pool -- spread evenly over it); grip_leaderboard_scan_bounded marks every un-refined row that takes part in a comparison the bound
+    the pool, at least 16 -- spread evenly over it); grip_leaderboard_scan_bounded marks every un-refined row that takes part in a comparison the bound
     cannot decide; those rows are re-encoded exactly and the scan repeats until nothing is marked and the bound has not moved.
     The final scan takes, decision by decision, the decisions of the scan over the all-f32 probabilities, so the lists are the
     exact mode's lists (asserted at N = 50 000 in tests/test_gpu_identical.py) at a fraction of its cost.
@@ -82,7 +85,8 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     stats = {"rows": n, "calibration_rows": 0, "rounds": 0, "scans": 0}
     if n == 0:
         return np.empty(0, np.int32), np.empty(0, np.int32), dict(stats, rows_refined=0, eps=0.0, max_deviation=0.0)
-    refine(np.unique(np.linspace(0, n - 1, max(1, min(calib, n // 16))).astype(np.int64)))      # at most 1/16 of a small pool
+    # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than 16 (a bound from one or two rows is no bound)
+    refine(np.unique(np.linspace(0, n - 1, min(n, max(16, min(calib, n // 16)))).astype(np.int64)))
     stats["calibration_rows"] = int(refined.sum())
     eps = safety * dev_max
     per_round = []
@@ -95,6 +99,11 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
             break
         if stats["rounds"] >= max_rounds:
             raise RuntimeError(f"refine_scan: no fixed point after {max_rounds} rounds ({int(refined.sum())} of {n} rows refined)")
+        if stats["rounds"] >= REFINE_ESCALATE_AFTER:
+            # Heavily tied scores can keep a board in the reference's unsorted regime, where every comparison has to be certain and a
+            # round only advances a few images in dataset order: stop trickling and take the exact tower to everything that is left.
+            todo = np.flatnonzero(~refined)
+            stats["escalated"] = True
         refine(todo)
         per_round.append(int(todo.size))
         stats["rounds"] += 1

@@ -153,3 +153,38 @@ def test_bounded_scan_with_zero_bound_is_the_plain_scan():
         img, cls, amb = engine.leaderboard_scan_bounded(p32, a32, ranks, np.zeros(len(paths), np.float32), k)
         i2, c2 = engine.leaderboard_scan(p32, a32, ranks, k)
         assert not amb.any() and np.array_equal(img, i2) and np.array_equal(cls, c2)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_fuzz_against_the_c_oracle(block):
+    """Random pools over the whole parameter space -- sizes, class counts, k, score spreads from near-uniform to peaked, deviations
+    from 1e-4 to 5e-2, quantised scores (exact ties), duplicate paths, one dominant class, class-structured rows -- each refined
+    to its fixed point and compared with the plain-C restatement of the reference scan on the exact matrix.  (tools-free copy of the
+    1 600-case sweep the conditional-offer rule was validated with.)"""
+    from oracle import cbind
+    r = np.random.RandomState(7000 + block)
+    for _ in range(40):
+        n = int(r.choice([30, 200, 1000, 4000])); c = int(r.choice([2, 3, 5, 8, 20])); k = int(r.choice([1, 2, 3, 8, 16]))
+        spread = float(r.choice([0.02, 0.1, 0.3, 1.0, 3.0])); sigma = float(r.choice([1e-4, 1e-3, 1e-2, 5e-2]))
+        q = int(r.choice([0, 0, 16, 200])); dom = bool(r.randint(2)); dup = bool(r.randint(2))
+        seed = int(r.randint(1 << 30))
+        p32, a32, p16, a16, paths = _pool(n, c, spread, sigma, seed, q, dup, dom)
+        if r.randint(2):      # class-structured: each row gets one boosted class, so several classes own arg-maxes
+            lg = np.log(p32.astype(np.float64)) + (r.randn(n, 1) * 0.5) * (np.arange(c) == r.randint(0, c, size=(n, 1)))
+            z = np.exp(lg - lg.max(1, keepdims=True))
+            p32 = (z / z.sum(1, keepdims=True)).astype(np.float32)
+            p16 = (p32.astype(np.float64) * (1.0 + np.clip(r.randn(n, c), -5, 5) * sigma)).astype(np.float32)
+            a32, a16 = p32.argmax(1).astype(np.int32), p16.argmax(1).astype(np.int32)
+        want = cbind.leaderboard_ref(p32, a32, paths, list(range(c)), k)
+        got, st = _refine(p32, a32, p16, a16, paths, k, calib=int(r.choice([8, 64, 256])))
+        assert got == want, (n, c, k, spread, sigma, q, dom, dup, seed, st)
+
+
+def test_tied_scores_escalate_instead_of_trickling():
+    """Eleven distinct score values, k = 1: boards stay in the reference's unsorted regime (an equal score never overflows them), every
+    comparison there has to be certain and a round advances only a few images -- after 8 rounds the rest is re-encoded at once."""
+    from oracle import cbind
+    p32, a32, p16, a16, paths = _pool(4000, 8, 0.3, 0.01, 707040913, 16, False, True)
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(8)), 1)
+    got, st = _refine(p32, a32, p16, a16, paths, 1, calib=8)
+    assert got == want and st.get("escalated") and st["rounds"] <= 10

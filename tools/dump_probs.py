@@ -22,10 +22,21 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--pool", type=int, default=50000)
 ap.add_argument("--classes", type=int, default=102)
 ap.add_argument("--structured", action="store_true")
+ap.add_argument("--structured-device", action="store_true", help="bench.py's device-generated structured pool (secondary.identical_on_structured_pool)")
 ap.add_argument("--out", default="gpurun_out/probs_dump.npz")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-if a.structured:
+if a.structured_device:
+    g = torch.Generator(device=dev).manual_seed(4242)
+    pool = torch.empty(a.pool, 3, 224, 224, device=dev)
+    ramp = torch.linspace(-1.0, 1.0, 224, device=dev).view(1, 1, 1, -1)
+    for lo in range(0, a.pool, 2048):
+        hi = min(lo + 2048, a.pool)
+        x = torch.empty(hi - lo, 3, 224, 224, device=dev).normal_(generator=g)
+        mu = torch.empty(hi - lo, 3, 1, 1, device=dev).normal_(generator=g) * 2.0
+        r = torch.empty(hi - lo, 3, 1, 1, device=dev).normal_(generator=g)
+        pool[lo:hi] = x * 0.5 + mu + ramp * r
+elif a.structured:
     from grip_amd.data.synthetic import structured_images
     pool = torch.empty(a.pool, 3, 224, 224, device=dev)
     for lo in range(0, a.pool, 500):
