@@ -264,13 +264,13 @@ class Loop:
 
 
 # ------------------------------------------------------------------------------------------------ GEMM profiler helpers
-N_SLOTS = 112   # slot = variant * 16 + epilogue id (csrc/gemm.hip)
+N_SLOTS = 144   # slot = variant * 16 + epilogue id (csrc/gemm.hip)
 
 
 def kname(slot):
     v, e = divmod(slot, 16)
     return {0: f"gemm_f32_kernel<{e}>", 1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
-            5: f"gemm_k64_kernel<{e}, 8>", 6: f"gemm_k64p_kernel<{e}>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e] if e < len(EPI_NAMES) else e}]"
+            5: f"gemm_k64_kernel<{e}, 8, 8>", 6: f"gemm_k64p_kernel<{e}>", 8: f"gemm_k64_kernel<{e}, 8, 6>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e] if e < len(EPI_NAMES) else e}]"
 
 
 def profile_collect(lib):

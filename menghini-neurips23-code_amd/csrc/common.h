@@ -163,6 +163,10 @@ struct GemmArgs {
     // in a fixed order (launch_ln_bwd_add).  gemm_pick_ksplit chooses the factor.
     int ksplit;
     int64_t split_stride;
+    // One-tile-per-workgroup kernels: tile row tm starts its K walk rot_rows * tm slices further on (0: every tile row starts where its
+    // column panel says).  Changes the summation order with the tile row, so only train-mode launches may set it (the inference
+    // forwards stay bit-identical under any chunking).
+    int rot_rows;
 };
 int gemm_pick_ksplit(int M, int N, int K);
 

@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_m, 
             g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
         }
     }
-    const int rot = gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk);
+    const int rot = ((gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk)) + tm * g.rot_rows) % nk;
     auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
     stage(0, kt0 + ks(0));
     for (int kt = 0; kt < nk; ++kt) {
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
             g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
         }
     }
-    const int rot = gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk);
+    const int rot = ((gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk)) + tm * g.rot_rows) % nk;
     auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) stage(t, kt0 + ks(t));
@@ -721,6 +721,138 @@ __global__ __launch_bounds__(256) void gemm_ring_kernel(GemmArgs g, int tiles_m,
     }
 
     __syncthreads();   // every wave is done with the ring: reuse it as epilogue slabs
+    epilogue_rows<EPI, WMF>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The ring with the feed on its own waves (r03).  Measured (tools/micro/dma_feed_small.hip, tools/exp_r03_5.sh): a CU pulls ~80 GB/s
+// through global_load_lds whatever the number of issuing waves or the ring depth, and a wave that issues a piece while that path is
+// busy sits in the issue stage until the piece is accepted -- so in gemm_ring_kernel, where the same four waves issue the loads AND the
+// MFMAs, feed time and compute time ADD UP (64x128 tiles, K = 3 072, one workgroup per CU: 15.6 us of feed alone, 11.7 us of fragment
+// reads and MFMAs alone, 26 us together).  Here waves 4..7 only issue the loads (and are the ones that block), waves 0..3 only read
+// fragments and multiply, software-pipelined over the two 32-wide halves of a K tile (the reads of one half are in flight under the
+// MFMAs of the other); one barrier per K tile joins the two groups.  WMF = 2: 64x128 tile (24 KiB stages, up to 6), WMF = 4: 128x128
+// (32 KiB stages, up to 5).  Same products in the same order as every other kernel of this file: bit-identical results.
+template <int EPI, int NST, int WMF>
+__global__ __launch_bounds__(512) void gemm_ringw_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int BMT = 32 * WMF;
+    constexpr int STAGE = (BMT + BN) * BK;       // halfs
+    constexpr int GA = BMT / 32;
+    constexpr int G = GA + 4;                    // global_load_lds per producer wave per tile
+    extern __shared__ __attribute__((aligned(16))) half_t lds2[];
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BMT, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int nk = g.K / BK, kt0 = 0;                   // nk >= NST - 1 (launcher)
+    if constexpr (EPI == EPI_F32) {
+        if (gridDim.y > 1) {                      // split-K: k tiles [kt0, kt0 + nk) into partial buffer blockIdx.y
+            nk /= (int)gridDim.y;
+            kt0 = (int)blockIdx.y * nk;
+            g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
+        }
+    }
+    const int rot = ((gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk)) + tm * g.rot_rows) % nk;
+    auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
+
+    if (wave >= 4) {
+        // ---- producers: wave 4 + w fills rows [w*BMT/4, +BMT/4) of the A tile and rows [w*32, +32) of the W tile, 8 rows (1 KiB) per
+        // instruction; lane l -> row l>>3, LDS chunk l&7, source chunk (l&7)^(l>>3)  (the layout of gemm_f16_kernel)
+        const int pw = wave - 4;
+        const int srow = lane >> 3;
+        const int schunk = (lane & 7) ^ srow;
+        const size_t K = (size_t)g.K;
+        const half_t* a_src = (const half_t*)g.A + (size_t)(m0 + pw * (BMT / 4)) * K;
+        const half_t* w_src = (const half_t*)g.W + (size_t)(n0 + pw * 32) * K;
+        const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
+        auto stage = [&](int buf, int kt) {
+            half_t* abase = lds2 + buf * STAGE + pw * (BMT / 4) * BK;
+            half_t* bbase = lds2 + buf * STAGE + BMT * BK + pw * 32 * BK;
+            const half_t* as = a_src + (size_t)kt * BK;
+            const half_t* ws = w_src + (size_t)kt * BK;
+#pragma unroll
+            for (int i = 0; i < GA; ++i)
+                __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(as + (size_t)i * 8 * K) + lane_off), (AS3 void*)(abase + i * 8 * BK), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(ws + (size_t)i * 8 * K) + lane_off), (AS3 void*)(bbase + i * 8 * BK), 16, 0, 0);
+        };
+#pragma unroll
+        for (int t = 0; t < NST - 1; ++t) stage(t, kt0 + ks(t));
+        wait_vmcnt<(NST - 2) * G>();                  // tile 0 (nk >= NST - 1: NST - 2 younger tiles are in flight)
+        __builtin_amdgcn_s_barrier();
+        int nbuf = NST - 1;                           // slot the tile kt + NST - 1 goes to (= the slot of tile kt - 1)
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                // tile kt + 1 has landed: issued so far are the tiles up to min(nk - 1, kt + NST - 2)
+                const int younger = nk - 2 - kt;
+                if (younger >= NST - 3) wait_vmcnt<(NST - 3) * G>();
+                else if (NST > 5 && younger == 2) wait_vmcnt<2 * G>();
+                else if (NST > 4 && younger == 1) wait_vmcnt<G>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();         // ... and the consumers are through step kt - 1: the slot of tile kt - 1 is free
+            }
+            if (kt + NST - 1 < nk) stage(nbuf, kt0 + ks(kt + NST - 1));
+            nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+        }
+        __builtin_amdgcn_s_barrier();                 // (the consumers' "ring is free" barrier)
+        return;
+    }
+
+    // ---- consumers: 2 x 2 waves, each (WMF x 16) x 64 of the tile
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 15, fgrp = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
+        a_off[kk] = (wr * WMF * 16 + frow) * BK + chunk * 8;
+        b_off[kk] = BMT * BK + (wc * 64 + frow) * BK + chunk * 8;
+    }
+    f32x4 acc[WMF][4];
+    init_acc<EPI, WMF>(g, acc, n0 + wc * 64, lane);
+    half8 fa[2][WMF], fb[2][4];
+    auto rd = [&](const half_t* st, int kk) {
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) fa[kk][i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[kk][j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
+    };
+    auto mm = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < WMF; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();                     // tile 0 is in LDS
+    rd(lds2, 0);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = buf + 1 == NST ? 0 : buf + 1;
+        if (kt + 1 < nk) __builtin_amdgcn_s_barrier();   // tile kt + 1 is in LDS; every consumer is through step kt - 1
+        __builtin_amdgcn_sched_barrier(0);
+        rd(lds2 + buf * STAGE, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) rd(lds2 + nxt * STAGE, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nxt;
+    }
+    __builtin_amdgcn_s_barrier();   // every consumer is done with the ring: reuse it as epilogue slabs
     epilogue_rows<EPI, WMF>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane);
 }
 
@@ -934,9 +1066,11 @@ __global__ __launch_bounds__((BMT / 128) * (BNT / 64) * 64, 2) void gemm_big_ker
 // fragments are fetched under the second sub-step's MFMAs.  NW = 8: waves 128x64, two per SIMD.  (A four-wave build of this and of the ring -- 128x128 per wave, accumulators in
 // the 256 AGPRs, a third less LDS fragment traffic -- measured 5-25 % slower: one wave per SIMD leaves the barrier, DMA
 // issue and epilogue uncovered.)
-template <int EPI, int NW>
+// RF = 16-row fragments per wave along M: 8 -> 256x256 tile; 6 -> 192x256 (r03: launches of fewer tiles than CUs run one tile-time whatever
+// the tile holds, so M = 3 408 rows as 18 row panels of 192 on 216 CUs beat 14 panels of 256 on 168).
+template <int EPI, int NW, int RF = 8>
 __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-    constexpr int BMT = 256, BNT = 256;
+    constexpr int BMT = 32 * RF, BNT = 256;
     constexpr int WN = NW / 2;                    // waves along N
     constexpr int WCOLS = BNT / WN;               // 64 or 128
     constexpr int NJ = WCOLS / 16;
@@ -963,15 +1097,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
     const size_t K = (size_t)g.K;
-    const int r0 = wave * GI * 8;                 // uniform: this wave's rows are all A rows or all W rows (GI*8 divides 256)
+    const int r0 = wave * GI * 8;                 // uniform; RF = 8: this wave's rows are all A rows or all W rows (GI*8 divides 256)
     const half_t* src = r0 < BMT ? (const half_t*)g.A + (size_t)(m0 + r0) * K : (const half_t*)g.W + (size_t)(n0 + r0 - BMT) * K;
+    const half_t* src_w = (const half_t*)g.W + ((ptrdiff_t)n0 + r0 - BMT) * (ptrdiff_t)K;      // RF != 8: the wave whose pieces straddle the A / W boundary
     const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
     auto stage = [&](int buf, int kt) {
         half_t* dst = lds2 + buf * STAGE + r0 * BK;
         const half_t* sp = src + (size_t)kt * BK;
+        const half_t* spw = src_w + (size_t)kt * BK;
 #pragma unroll
-        for (int i = 0; i < GI; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(sp + (size_t)i * 8 * K) + lane_off), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
+        for (int i = 0; i < GI; ++i) {
+            const half_t* row = (RF == 8 || r0 + i * 8 < BMT) ? sp : spw;     // (uniform select)
+            __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(row + (size_t)i * 8 * K) + lane_off), (AS3 void*)(dst + i * 8 * BK), 16, 0, 0);
+        }
     };
 
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -979,39 +1117,39 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
-        a_off[kk] = (wr * 128 + frow) * BK + chunk * 8;
+        a_off[kk] = (wr * RF * 16 + frow) * BK + chunk * 8;
         b_off[kk] = BMT * BK + (wc * WCOLS + frow) * BK + chunk * 8;
     }
 
-    f32x4 acc[NJ / 4][8][4];
+    f32x4 acc[NJ / 4][RF][4];
 #pragma unroll
-    for (int h = 0; h < NJ / 4; ++h) init_acc<EPI, 8>(g, acc[h], n0 + wc * WCOLS + h * 64, lane);
+    for (int h = 0; h < NJ / 4; ++h) init_acc<EPI, RF>(g, acc[h], n0 + wc * WCOLS + h * 64, lane);
 
-    half8 fa[2][8], fb[2][NJ];
+    half8 fa[2][RF], fb[2][NJ];
     auto load_frags = [&](int set, int buf, int kk) {
         const half_t* st = lds2 + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) fb[set][j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[set][i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+        for (int i = 0; i < RF; ++i) fa[set][i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
     };
     auto mfma_set = [&](int set) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < RF; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 acc[j >> 2][i][j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[set][j], fa[set][i], acc[j >> 2][i][j & 3], 0, 0, 0);
     };
-    auto spread = [&]() {     // interleave the (8 + NJ) fragment reads of the other set with this set's 8*NJ MFMAs
+    auto spread = [&]() {     // interleave the (RF + NJ) fragment reads of the other set with this set's RF*NJ MFMAs
 #pragma unroll
-        for (int q = 0; q < 8 + NJ; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, (8 * NJ) / (8 + NJ) > 3 ? 3 : 2, 0);
+        for (int q = 0; q < RF + NJ; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (RF * NJ) / (RF + NJ) > 3 ? 3 : 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
     };
 
     const int nk = g.K / BK;    // >= 2 (checked by the launcher)
-    const int rot = k_rot(tn, tiles_n, nk);
+    const int rot = (k_rot(tn, tiles_n, nk) + tm * g.rot_rows) % nk;
     auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
     stage(0, ks(0));
     stage(1, ks(1));
@@ -1038,7 +1176,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
     __builtin_amdgcn_s_barrier();   // every wave is done with the stages: reuse them as epilogue slabs
 #pragma unroll
     for (int h = 0; h < NJ / 4; ++h)
-        epilogue_rows<EPI, 8, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc[h], (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * 128, n0 + wc * WCOLS + h * 64, lane);
+        epilogue_rows<EPI, RF, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc[h], (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * RF * 16, n0 + wc * WCOLS + h * 64, lane);
 }
 
 // ---- Persistent form of gemm_k64_kernel: one workgroup per CU walks its XCD's run of tiles, and the two-stage K pipeline
@@ -1299,7 +1437,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
 #include <deque>
 #include <vector>
 namespace {
-constexpr int PROF_RING = 4096, PROF_EPIS = 112;   // slot = variant * 16 + epilogue id (variants 1..6)
+constexpr int PROF_RING = 4096, PROF_EPIS = 144;   // slot = variant * 16 + epilogue id (variants 0..8)
 struct ProfRec { int epi; double flops; hipEvent_t a, b; };
 bool g_prof = false;
 std::deque<ProfRec> g_recs;
@@ -1403,19 +1541,20 @@ static int launch_big(int epi, const GemmArgs& a, hipStream_t s) {
     return GRIP_OK;
 }
 
-template <int NW>
+template <int NW, int RF = 8>
 static int launch_k64(int epi, const GemmArgs& a, hipStream_t s) {
-    const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
-    constexpr size_t lds = (size_t)2 * 512 * BK * 2;
+    constexpr int BMT = 32 * RF;
+    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.N / 256;
+    constexpr size_t lds = (size_t)2 * (BMT + 256) * BK * 2;
     dim3 grid(tiles_m * tiles_n), block(NW * 64);
 #define GRIP_GEMM_CASE(E)                                                                                                   \
     case E: {                                                                                                               \
         static bool configured = false;                                                                                     \
         if (!configured) {                                                                                                  \
-            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64_kernel<E, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64_kernel<E, NW, RF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             configured = true;                                                                                              \
         }                                                                                                                   \
-        hipLaunchKernelGGL((gemm_k64_kernel<E, NW>), grid, block, lds, s, a, tiles_m, tiles_n);                             \
+        hipLaunchKernelGGL((gemm_k64_kernel<E, NW, RF>), grid, block, lds, s, a, tiles_m, tiles_n);                             \
     } break;
     switch (epi) {
         GRIP_GEMM_CASE(EPI_F32)
@@ -1602,7 +1741,50 @@ static int launch_ring(int epi, const GemmArgs& a, int nst, dim3 grid, hipStream
     return GRIP_OK;
 }
 
-static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chosen) {
+// gemm_ringw_kernel: WMF = 2 (64-row tiles) runs a 4-slot ring, WMF = 4 (128-row tiles) a 3-slot ring for short K walks and a 5-slot one
+// (the whole LDS) for long ones
+template <int WMF, int NST>
+static int launch_ringw(int epi, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int BMT = 32 * WMF;
+    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.N / BN;
+    constexpr size_t lds = (size_t)NST * (BMT + BN) * BK * 2;
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_ringw_kernel<E, NST, WMF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_ringw_kernel<E, NST, WMF>), grid, dim3(512), lds, s, a, tiles_m, tiles_n);                  \
+    } break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
+        GRIP_GEMM_CASE(EPI_F16)
+        GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
+        GRIP_GEMM_CASE(EPI_F32_SCALE)
+        GRIP_GEMM_CASE(EPI_LNFOLD_F16)
+        GRIP_GEMM_CASE(EPI_LNFOLD_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_STATS)
+        default: GRIP_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* chosen) {
+    // Row-dependent K rotation (GemmArgs::rot_rows = the caller's permission: train-mode launches only).  In a prompt step every GEMM
+    // reads weights nobody has touched since the previous step; with all tile rows of a column panel walking K in lockstep, each of them
+    // waits out the memory latency of every slice.  Staggered, a slice is fetched by one tile row and found in the L2 by the next: VPT
+    // step in situ (rocprofv3, tools/exp_r03_5.sh), GEMM time per step 2 245 us -> 2 025 us with a stride of 2 slices per tile row
+    // (1: 2 050, 3: 2 057, 5: 2 055, 11: 2 053); the split-K launches like 1 best (their walks are half or a third as long).
+    // GRIP_KROT_M: developer A/B (-1 = off, n > 0 = stride n).
+    static const int rot_m = getenv("GRIP_KROT_M") ? atoi(getenv("GRIP_KROT_M")) : 0;
+    GemmArgs a = a_in;
+    a.rot_rows = (a.rot_rows && !a.f32 && rot_m >= 0) ? (rot_m > 0 ? rot_m : (a.ksplit > 1 ? 1 : 2)) : 0;
     if (a.f32) {        // exact mode: f32 operands (gemm_f32.hip); profiler variant 0
         *chosen = 0;
         return launch_gemm_f32(epi, a, s);
@@ -1628,6 +1810,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
             // a CU stages per step), which the 64-row tile cuts by a quarter (measured at M = 425 and 2 142: 6-25 % faster)
             if (tm128 * (a.N / 128) <= 256) s4 = 1.0;
             if (s4 > best) { best = s4; variant = 4; }
+            // ... unless the 64-row tiles outnumber the CUs while the 128-row ones do not: one round of 128-row tiles on dedicated loader
+            // waves (gemm_ringw_kernel) beats a round and a bit of 64-row ones (M = 3 408, N = 768, K = 3 072: 25.6 us against 31)
+            static const bool r128 = !(getenv("GRIP_GEMM_R128") && atoi(getenv("GRIP_GEMM_R128")) == 0);     // developer A/B
+            if (r128 && variant == 4 && a.ksplit <= 1 && tm128 * (a.N / 128) <= 256 && (int64_t)((a.M + 63) / 64) * (a.N / 128) > 256 && a.K >= 2 * BK) { best = 1.0; variant = 1; }
         }
         if (can_big) {
             const double s3 = 0.93 * fill(tm256 * (a.N / 128), 512);
@@ -1638,6 +1824,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
                 // ... and persistent (one workgroup per CU walking its XCD's tiles) once every CU gets several tiles
                 static const int force = getenv("GRIP_GEMM_BIG") ? atoi(getenv("GRIP_GEMM_BIG")) : 0;    // developer A/B: 2, 5 or 6
                 if (s2 > best) { best = s2; variant = force ? force : (a.K < 2 * BK ? 2 : (tm256 * (a.N / 256) >= 512 ? 6 : 5)); }
+                // fewer tiles than CUs: one tile-time whatever the tile holds, so the 192-row form of the same kernel when it fills more CUs
+                const int64_t tm192 = (a.M + 191) / 192;
+                if (variant == 5 && !force && tm192 * 192 <= a.m_pad && tm192 * (a.N / 256) <= 256 && epi != EPI_BIAS_RESID_STATS &&
+                    fill(tm192 * (a.N / 256), 256) > best) { best = fill(tm192 * (a.N / 256), 256); variant = 8; }
             }
         }
     }
@@ -1665,9 +1855,22 @@ static int launch_gemm_impl(int epi, const GemmArgs& a, hipStream_t s, int* chos
         GRIP_REQUIRE(can_big && a.N % 256 == 0 && a.K >= 2 * BK, "gemm: 256x256x64 tile needs N %% 256 == 0, K >= 128 and A padded to 256 rows");
         return launch_k64p(epi, a, s);
     }
+    if (variant == 8) {      // (7 is the f32 kernel in the debug hook)
+        GRIP_REQUIRE(a.N % 256 == 0 && a.K >= 2 * BK && (int64_t)((a.M + 191) / 192) * 192 <= a.m_pad && epi != EPI_BIAS_RESID_STATS,
+                     "gemm: 192x256x64 tile needs N %% 256 == 0, K >= 128, A padded to a multiple of 192 rows and an epilogue without row statistics");
+        return launch_k64<8, 6>(epi, a, s);
+    }
     const int bmt = variant == 4 ? 64 : 128;
     const int tiles_m = (a.M + bmt - 1) / bmt, tiles_n = a.N / BN;
     dim3 grid(tiles_m * tiles_n, ksplit), block(256);
+    // At most one workgroup per CU: the ring with the feed on its own waves (gemm_ringw_kernel).  GRIP_GEMM_WSPEC=0: developer A/B.
+    static const bool wspec = !(getenv("GRIP_GEMM_WSPEC") && atoi(getenv("GRIP_GEMM_WSPEC")) == 0);
+    if (wspec && (int64_t)grid.x * ksplit <= 256) {
+        const int nk = a.K / BK / ksplit;
+        if (variant == 4 && nk >= 3) return launch_ringw<2, 4>(epi, a, grid, s);
+        if (variant == 1 && nk > 12) return launch_ringw<4, 5>(epi, a, grid, s);
+        if (variant == 1 && nk >= 2) return launch_ringw<4, 3>(epi, a, grid, s);
+    }
     if (variant == 4) {
         // ring depth by workgroups per CU: <= 1 -> four stages (96 KiB), <= 2 -> three (72 KiB, two per CU); beyond that three
         // co-resident two-stage workgroups already keep three tiles in flight per CU

@@ -408,6 +408,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         resid_t* x_mid = w.train ? w.x_mid[(size_t)l] : x;
         resid_t* x_out = w.train ? w.x_in[(size_t)l + 1] : x;
         GemmArgs a{};
+        a.rot_rows = w.train;     // train-mode GEMMs may stagger their K walks by tile row (common.h)
         if (!fold) {
             RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, f, w.M, d, s));
             a.f32 = f; a.A = w.xn; a.W = t->wop(lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
@@ -421,10 +422,12 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s, w.Ps));
         }
         a = GemmArgs{};
+        a.rot_rows = w.train;
         a.f32 = f; a.A = att; a.W = t->wop(lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
         a.stat_part = fold ? w.stat_part : nullptr;
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         a = GemmArgs{};
+        a.rot_rows = w.train;
         if (!fold) {
             RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, f, w.M, d, s));
             a.f32 = f; a.A = w.xn; a.W = t->wop(lw.fc_w); a.bias = F + lw.fc_b;
@@ -436,6 +439,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         a.out2 = w.train ? w.hpre_l[(size_t)l] : nullptr;
         RUN(launch_gemm(fold ? EPI_LNFOLD_GELU_F16 : EPI_BIAS_GELU_F16, a, s));
         a = GemmArgs{};
+        a.rot_rows = w.train;
         a.f32 = f; a.A = w.h; a.W = t->wop(lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
         a.stat_part = (!fold || last) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
@@ -534,10 +538,11 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
 extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid,
                                const void* aux, void* out, void* out2, float scalar, int m_pad, int variant, void* stream) {
     GemmArgs a{};
-    a.variant = variant;
+    a.variant = variant & 0xff;
+    a.rot_rows = (variant >> 8) & 1;                  // bit 8: the train-mode launches' row-dependent K rotation
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid;
     a.aux = aux; a.out = out; a.out2 = out2; a.ldc = N; a.scalar = scalar;
-    if (variant == 7) { a.f32 = 1; a.variant = 0; }   // f32 operands: the exact-mode kernel (gemm_f32.hip)
+    if (a.variant == 7) { a.f32 = 1; a.variant = 0; } // f32 operands: the exact-mode kernel (gemm_f32.hip)
     return launch_gemm(epi, a, (hipStream_t)stream);
 }
 // Split-K EPI_F32 product: out holds `ksplit` partial [M, N] buffers `split_stride` floats apart (ksplit = 0: the launcher's
@@ -545,7 +550,8 @@ extern "C" int grip_debug_gemm(int epi, const void* A, const void* W, int M, int
 extern "C" int grip_debug_gemm_splitk(const void* A, const void* W, int M, int N, int K, float* out, int ksplit, int64_t split_stride, int* ksplit_used,
                                       int m_pad, int variant, void* stream) {
     GemmArgs a{};
-    a.variant = variant;
+    a.variant = variant & 0xff;
+    a.rot_rows = (variant >> 8) & 1;
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.out = out; a.ldc = N;
     a.ksplit = ksplit ? ksplit : gemm_pick_ksplit(M, N, K);
     a.split_stride = split_stride;
@@ -587,19 +593,23 @@ static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, hipStrea
     for (int l = t->D.layers - 1; l >= 0; --l) {
         const LayerW& lw = t->L.layer[(size_t)l];
         GemmArgs a{};
+        a.rot_rows = 1;           // (backward GEMMs: train mode by definition)
         // d(pre-activation) = (dx @ W_proj) * quickgelu'(h_pre)
         a.A = w.dxh; a.W = W + lw.proj_wT; a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.aux = w.hpre_l[(size_t)l]; a.out = w.dh; a.ldc = 4 * d;
         RUN(launch_gemm(EPI_GELUGRAD_F16, a, s));
         a = GemmArgs{};
+        a.rot_rows = 1;
         a.A = w.dh; a.W = W + lw.fc_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.out = w.dln; a.ldc = d;
         a.ksplit = w.ks_fc; a.split_stride = part;
         RUN(launch_gemm(EPI_F32, a, s));
         RUN(launch_ln_bwd_add(w.x_mid[(size_t)l], w.dln, w.ks_fc, part, F + lw.ln2_g, w.dx, w.dxh, w.M, d, s));
         a = GemmArgs{};
+        a.rot_rows = 1;
         a.A = w.dxh; a.W = W + lw.out_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.out = w.datt; a.ldc = d;
         RUN(launch_gemm(EPI_F16, a, s));
         RUN(launch_attention_bwd(w.qkv_l[(size_t)l], w.att_l[(size_t)l], w.datt, w.dqkv, w.batch, w.S, H, causal, s, w.Ps, w.kv_part));
         a = GemmArgs{};
+        a.rot_rows = 1;
         a.A = w.dqkv; a.W = W + lw.in_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 3 * d; a.out = w.dln; a.ldc = d;
         a.ksplit = w.ks_in; a.split_stride = part;
         RUN(launch_gemm(EPI_F32, a, s));

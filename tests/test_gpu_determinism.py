@@ -32,10 +32,13 @@ def test_forward_backward_are_bit_reproducible():
     for _ in range(3):
         for u, v in zip(first, run()):
             assert torch.equal(u, v)
-    # per-image outputs do not depend on what else is in the batch -- within a mode: the train-mode forward keeps LayerNorm -> GEMM,
-    # the inference forward folds the LayerNorms into the GEMMs (csrc/tower.hip run_blocks); each is row-independent
+    # Per-image outputs of the INFERENCE forward do not depend on what else is in the batch, bit for bit (the pool encode under any
+    # chunking).  The train-mode forward keeps LayerNorm -> GEMM and, since r03, lets a GEMM's tile rows start their K walks at
+    # different slices (csrc/gemm.hip, GemmArgs::rot_rows): a row's f32 summation order depends on the tile row it lands in, so a
+    # sub-batch agrees with the full batch to accumulation-order accuracy only (as the reference's cuBLAS calls do).
     sub_train = VitPrefixFn.apply(m.visual.tower, x[5:13], vp.clone().requires_grad_(True)).detach()
-    assert torch.equal(sub_train, first[0][5:13])
+    cos_t = torch.nn.functional.cosine_similarity(sub_train, first[0][5:13], dim=-1)
+    assert (1 - cos_t).max().item() <= 1e-6 and ((sub_train - first[0][5:13]).norm() / first[0][5:13].norm()).item() <= 2e-3
     with torch.no_grad():
         full, sub = m.visual(x, vp), m.visual(x[5:13], vp)
     assert torch.equal(sub, full[5:13])

@@ -28,12 +28,14 @@ def quick_gelu(x):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (3408, 2304, 768), (77 * 5, 512, 2048), (16, 512, 768),
                                    (50432, 768, 768), (12700, 2304, 768), (25000, 768, 3072), (16500, 3072, 768), (50000, 512, 128)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8])
 def test_gemm_epilogues(M, N, K, variant):
-    if variant in (2, 5, 6) and N % 256:
+    if variant in (2, 5, 6, 8) and N % 256:
         pytest.skip("256x256 tile needs N % 256 == 0")
-    if variant in (2, 3, 5, 6) and K < 128:
+    if variant in (2, 3, 5, 6, 8) and K < 128:
         pytest.skip("ring needs K >= 128")
+    if variant == 8 and (M + 191) // 192 * 192 > (M + 255) // 256 * 256:
+        pytest.skip("192-row tiles need A padded to a multiple of 192 rows")
     native, lib = _lib()
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
     Mp = (M + 255) // 256 * 256     # rows allocated for A: lets the launcher pick the 256-row tile for large problems
@@ -86,6 +88,41 @@ def test_gemm256_is_not_transposed(variant):
     out = torch.zeros(M, N, device="cuda")
     native.check(lib.grip_debug_gemm(0, _p(A), _p(W), M, N, K, None, None, None, _p(out), None, 1.0, M, variant, _stream()))
     torch.testing.assert_close(out, W.float().t()[idx % K])
+
+
+@pytest.mark.parametrize("M,N,K", [(3408, 768, 3072), (3408, 3072, 768), (2142, 512, 2048), (425, 512, 512), (3152, 2304, 768)])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 8])
+def test_gemm_row_rotation_of_the_train_mode_launches(M, N, K, variant):
+    """Train-mode GEMMs let tile row tm start its K walk 2 * tm (split-K: tm) slices further on (csrc/gemm.hip launch_gemm_impl, bit 8 of the
+    debug hook's variant): another summation order, the same product -- against the float64 product and against the unrotated launch."""
+    if variant in (5, 8) and N % 256:
+        pytest.skip("256-column tile")
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    Mp = (M + 255) // 256 * 256
+    if variant == 8 and (M + 191) // 192 * 192 > Mp:
+        pytest.skip("192-row tiles need A padded to a multiple of 192 rows")
+    A = torch.randn(Mp, K, device="cuda", generator=g).half()
+    A[M:] = float("nan")
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g).half()
+    ref = (A[:M].double() @ W.double().t() + bias.double() + resid.double())
+    outs = []
+    for rot in (0, 256):
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), None, _p(out), None, 1.0, Mp, variant | rot, _stream()))
+        torch.testing.assert_close(out.double(), ref, rtol=2e-3, atol=4e-3)
+        outs.append(out)
+    assert (outs[0].float() - outs[1].float()).abs().max().item() <= 4e-3
+    if variant in (0, 1, 4):      # split-K partial products (EPI_F32): the partials' sum is what ln_bwd_add consumes
+        used = ctypes.c_int(0)
+        sums = []
+        for rot in (0, 256):
+            part = torch.zeros(8, Mp, N, device="cuda")
+            native.check(lib.grip_debug_gemm_splitk(_p(A), _p(W), M, N, K, _p(part), 0, Mp * N, ctypes.addressof(used), Mp, variant | rot, _stream()))
+            sums.append(part[:max(used.value, 1), :M].sum(0))
+            torch.testing.assert_close(sums[-1].double(), A[:M].double() @ W.double().t(), rtol=1e-3, atol=2e-3)
 
 
 def test_gemm_is_not_transposed():

@@ -18,6 +18,7 @@ lib = native.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ONLY = os.environ.get("ONLY", "")
 SWEEP = os.environ.get("SWEEP", "0") == "1"      # also time every tile shape / split factor per line
 
 
@@ -34,37 +35,51 @@ def bench(f, reps=40):
 
 
 SHAPES = []
-for tag, M, d in (("text", 2142, 512), ("image", 3408, 768), ("shared", 425, 512)):
+IMAGE_M = int(os.environ.get("IMAGE_M", "3408"))      # 16 x (197 + 16) rows; 3152 = 16 x 197
+for tag, M, d in (("text", 2142, 512), ("image", IMAGE_M, 768), ("shared", 425, 512)):
     SHAPES += [(f"{tag} qkv fwd", 1, M, 3 * d, d), (f"{tag} out fwd", 3, M, d, d), (f"{tag} fc fwd", 2, M, 4 * d, d), (f"{tag} proj fwd", 3, M, d, 4 * d),
                (f"{tag} proj dgrad", 5, M, 4 * d, d), (f"{tag} fc dgrad", 0, M, d, 4 * d), (f"{tag} out dgrad", 4, M, d, d), (f"{tag} qkv dgrad", 0, M, d, 3 * d)]
 
 print(f"GRIP_GEMM_RING={os.environ.get('GRIP_GEMM_RING', 'auto')} GRIP_GEMM_KSPLIT={os.environ.get('GRIP_GEMM_KSPLIT', 'auto')} variant={variant}")
 total = {"text": 0.0, "image": 0.0, "shared": 0.0}
+COLD = int(os.environ.get("COLD", "1"))      # number of operand sets cycled through (>= 12 sets of ~50 MB defeat the 256 MiB Infinity Cache: the in-situ case)
 for name, epi, M, N, K in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     Mp = (M + 255) // 256 * 256
-    A = torch.randn(Mp, K, device="cuda").half()
-    W = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+    sets = []
+    for _ in range(COLD):
+        sets.append(dict(A=torch.randn(Mp, K, device="cuda").half(), W=(torch.randn(N, K, device="cuda") * K ** -0.5).half(), resid=torch.randn(M, N, device="cuda").half(),
+                         aux=torch.randn(M, N, device="cuda").half(), out=torch.empty(8 if epi == 0 else 1, Mp, N, device="cuda", dtype=torch.float32 if epi == 0 else torch.float16)))
     bias = torch.randn(N, device="cuda")
-    resid = torch.randn(M, N, device="cuda").half()
-    aux = torch.randn(M, N, device="cuda").half()
+    it = [0]
+
+    def nxt():
+        it[0] = (it[0] + 1) % COLD
+        return sets[it[0]]
     if epi == 0:
-        out = torch.empty(8, Mp, N, device="cuda")
         used = ctypes.c_int(0)
-        t = bench(lambda: native.check(lib.grip_debug_gemm_splitk(p(A), p(W), M, N, K, p(out), 0, Mp * N, ctypes.addressof(used), Mp, variant, s)))
+
+        def run(ks=0, v=variant):
+            d = nxt()
+            native.check(lib.grip_debug_gemm_splitk(p(d["A"]), p(d["W"]), M, N, K, p(d["out"]), ks, Mp * N, ctypes.addressof(used), Mp, v, s))
+        t = bench(run)
         extra = f"ksplit {used.value}"
         if SWEEP:
             for v in (1, 4):
                 for ks in (1, 2, 3, 4, 6, 8):
                     if (K // 64) % ks == 0:
-                        tt = bench(lambda: native.check(lib.grip_debug_gemm_splitk(p(A), p(W), M, N, K, p(out), ks, Mp * N, ctypes.addressof(used), Mp, v, s)))
+                        tt = bench(lambda: run(ks, v))
                         extra += f" | v{v} ks{ks} {tt:.1f}"
     else:
-        out = torch.empty(M, N, device="cuda", dtype=torch.float16)
-        t = bench(lambda: native.check(lib.grip_debug_gemm(epi, p(A), p(W), M, N, K, p(bias), p(resid), p(aux), p(out), None, 1.0, Mp, variant, s)))
+        def run(v=variant):
+            d = nxt()
+            native.check(lib.grip_debug_gemm(epi, p(d["A"]), p(d["W"]), M, N, K, p(bias), p(d["resid"]), p(d["aux"]), p(d["out"]), None, 1.0, Mp, v, s))
+        t = bench(run)
         extra = ""
         if SWEEP:
             for v in (1, 4, 3):
-                tt = bench(lambda: native.check(lib.grip_debug_gemm(epi, p(A), p(W), M, N, K, p(bias), p(resid), p(aux), p(out), None, 1.0, Mp, v, s)))
+                tt = bench(lambda: run(v))
                 extra += f" | v{v} {tt:.1f}"
     total[name.split()[0]] += t
     print(f"{name:18s} epi {epi} M={M} N={N} K={K}: {t:7.2f} us {2.0 * M * N * K / t / 1e6:6.0f} TF/s {extra}", flush=True)
