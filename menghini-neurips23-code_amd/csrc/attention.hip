@@ -419,8 +419,204 @@ __global__ __launch_bounds__(64) void attn_row_kernel(const half_t* __restrict__
     }
 }
 
-int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s) {
+// ---- The same with FOUR waves per (sequence, head): the train-mode last block (csrc/tower.hip), where a prompt-step batch gives the
+// one-wave form only B x H = 192 waves of ~200 dependent key trips (16 us for a 16-image batch).  Keys are dealt over 256 threads for the
+// scores and over 32 key groups for P.V; the block-wide max / sum / P.V partials meet in LDS and are combined in wave order.
+// Another summation order than attn_row_kernel, so the MODE picks the kernel, never the batch size (inference stays on the one-wave form:
+// a row is computed the same way in whatever chunk it arrives).
+__device__ __forceinline__ float block4_max(float v, float* red, int wave, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return v;
+}
+__device__ __forceinline__ float block4_sum(float v, float* red, int wave, int lane) {
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    v = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attn_row4_kernel(const half_t* __restrict__ qkv, const int32_t* __restrict__ row_index, half_t* __restrict__ out, int S, int H,
+                                                       int causal) {
+    extern __shared__ float sm[];         // [64] q / 8, [4] reduction, [4 x 64] P.V partials, [S] probabilities
+    float* qs = sm;
+    float* red = sm + 64;
+    float* pv = sm + 68;
+    float* ps = sm + 68 + 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * 64;
+    const size_t ld = (size_t)3 * D;
+    const int r = row_index ? row_index[b] : 0;
+    const half_t* base = qkv + (size_t)b * S * ld + h * 64;
+    if (tid < 64) qs[tid] = (float)base[(size_t)r * ld + tid] * 0.125f;
+    __syncthreads();
+    const int n_keys = causal ? r + 1 : S;
+    float m = -INFINITY;
+    for (int j = tid; j < n_keys; j += 256) {
+        const half8* kr = (const half8*)(base + (size_t)j * ld + D);
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half8 kv = kr[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qs[c * 8 + e], (float)kv[e], a);
+        }
+        ps[j] = a;
+        m = fmaxf(m, a);
+    }
+    m = block4_max(m, red, wave, lane);
+    float sum = 0.f;
+    for (int j = tid; j < n_keys; j += 256) {
+        const float p = __expf(ps[j] - m);
+        ps[j] = p;
+        sum += p;
+    }
+    sum = block4_sum(sum, red, wave, lane);      // (its barriers also publish ps)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int kg = tid >> 3, ch = tid & 7;
+    for (int j = kg; j < n_keys; j += 32) {
+        const half8 v = *(const half8*)(base + (size_t)j * ld + 2 * D + ch * 8);
+        const float p = ps[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)v[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8);
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (lane < 8)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[wave * 64 + ch * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) {
+        const float inv = 1.0f / sum;
+        out[(size_t)b * D + h * 64 + tid] = (half_t)((((pv[tid] + pv[64 + tid]) + pv[128 + tid]) + pv[192 + tid]) * inv);
+    }
+}
+
+// ---- Backward of attn_row_kernel (train-mode last block, csrc/tower.hip run_blocks_backward): ONE query row per sequence attends to
+// all keys, so dQ is one row, dK_j = dS_j q / 8 and dV_j = P_j dO are rank-one in the row's (q, dO), and every other query row of dQ is
+// zero.  Writes the whole packed [B, S, 3, H*64] gradient (zeros included), as the full attention backward would for a d_out that is
+// zero outside the read rows.  Four waves per (sequence, head), the thread maps of attn_row4_kernel: threads over keys for the scores and
+// dP = dO . V_j, (key group, 8-wide slice) for the outputs; dQ folds its 32 key groups with three xor-shuffles and one pass through LDS.
+__global__ __launch_bounds__(256) void attn_row_bwd_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ o_rows, const half_t* __restrict__ do_rows,
+                                                          const int32_t* __restrict__ row_index, half_t* __restrict__ dqkv, int S, int H, int causal) {
+    extern __shared__ float sm[];         // [64] q / 8, [64] dO, [4] reduction, [4 x 64] dQ partials, [S] probabilities, [S] dS
+    float* qs = sm;
+    float* dos = sm + 64;
+    float* red = sm + 128;
+    float* dqp = sm + 132;
+    float* ps = sm + 132 + 256;
+    float* dss = ps + S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * 64;
+    const size_t ld = (size_t)3 * D;
+    const int r = row_index ? row_index[b] : 0;
+    const half_t* base = qkv + (size_t)b * S * ld + h * 64;
+    half_t* dbase = dqkv + (size_t)b * S * ld + h * 64;
+    float dd = 0.f;
+    if (tid < 64) {
+        const float dov = (float)do_rows[(size_t)b * D + h * 64 + tid];
+        qs[tid] = (float)base[(size_t)r * ld + tid] * 0.125f;
+        dos[tid] = dov;
+        dd = dov * (float)o_rows[(size_t)b * D + h * 64 + tid];
+    }
+    const float delta = block4_sum(dd, red, wave, lane);      // rowsum(dO o O); its barriers publish qs / dos
+    const int n_keys = causal ? r + 1 : S;
+    float m = -INFINITY;
+    for (int j = tid; j < n_keys; j += 256) {
+        const half8* kr = (const half8*)(base + (size_t)j * ld + D);
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half8 kv = kr[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = __builtin_fmaf(qs[c * 8 + e], (float)kv[e], a);
+        }
+        ps[j] = a;
+        m = fmaxf(m, a);
+    }
+    m = block4_max(m, red, wave, lane);
+    float sum = 0.f;
+    for (int j = tid; j < n_keys; j += 256) {
+        const float p = __expf(ps[j] - m);
+        ps[j] = p;
+        sum += p;
+    }
+    sum = block4_sum(sum, red, wave, lane);
+    const float inv = 1.0f / sum;
+    for (int j = tid; j < n_keys; j += 256) {      // (each thread revisits the keys it wrote)
+        const half8* vr = (const half8*)(base + (size_t)j * ld + 2 * D);
+        float dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const half8 vv = vr[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dp = __builtin_fmaf(dos[c * 8 + e], (float)vv[e], dp);
+        }
+        const float pn = ps[j] * inv;
+        ps[j] = pn;
+        dss[j] = pn * (dp - delta);
+    }
+    __syncthreads();
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int kg = tid >> 3, ch = tid & 7;
+    const half8 zero = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    for (int j = kg; j < S; j += 32) {
+        half8 dk = zero, dv = zero;
+        if (j < n_keys) {
+            const half8 k = *(const half8*)(base + (size_t)j * ld + D + ch * 8);
+            const float ds = dss[j], p = ps[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e] = __builtin_fmaf(ds, (float)k[e], acc[e]);
+                dk[e] = (half_t)(ds * qs[ch * 8 + e]);          // qs carries the 1/8
+                dv[e] = (half_t)(p * dos[ch * 8 + e]);
+            }
+        }
+        *(half8*)(dbase + (size_t)j * ld + D + ch * 8) = dk;
+        *(half8*)(dbase + (size_t)j * ld + 2 * D + ch * 8) = dv;
+        if (j != r) *(half8*)(dbase + (size_t)j * ld + ch * 8) = zero;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8);
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (lane < 8)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dqp[wave * 64 + ch * 8 + e] = acc[e];
+    __syncthreads();
+    if (tid < 64) dbase[(size_t)r * ld + tid] = (half_t)((((dqp[tid] + dqp[64 + tid]) + dqp[128 + tid]) + dqp[192 + tid]) * 0.125f);
+}
+
+int launch_attention_row_bwd(const half_t* qkv, const half_t* o_rows, const half_t* do_rows, const int32_t* row_index, half_t* dqkv, int B, int S, int H, int causal,
+                             hipStream_t s) {
+    GRIP_REQUIRE(B >= 1 && S >= 1 && H >= 1, "attention_row_bwd: bad shape");
+    hipLaunchKernelGGL(attn_row_bwd_kernel, dim3(B * H), dim3(256), (size_t)(132 + 256 + 2 * S) * sizeof(float), s, qkv, o_rows, do_rows, row_index, dqkv, S, H, causal);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
+int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s, int train) {
     GRIP_REQUIRE(B >= 1 && S >= 1 && H >= 1, "attention_row: bad shape");
+    if (train) {      // four waves per (sequence, head): the prompt steps' small batches
+        GRIP_REQUIRE(!qrows, "attention_row: the train-mode form reads its queries from the packed projection");
+        hipLaunchKernelGGL(attn_row4_kernel, dim3(B * H), dim3(256), (size_t)(68 + 256 + S) * sizeof(float), s, qkv, row_index, out, S, H, causal);
+        GRIP_CHECK_HIP(hipGetLastError());
+        return GRIP_OK;
+    }
     hipLaunchKernelGGL(attn_row_kernel, dim3(B * H), dim3(64), (size_t)(64 + S) * sizeof(float), s, qkv, qrows, row_index, out, S, H, causal);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;

@@ -204,8 +204,12 @@ __device__ __forceinline__ size_t seq_row(int b, int r, int S, int Ps) {
 
 // shared_rows > 0: shared-prefix row layout (attention.hip, seq_row)
 int launch_attention_fwd(const half_t* qkv, half_t* out, int B, int S, int H, int causal, hipStream_t s, int shared_rows = 0);
-int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s);
+// train != 0: the four-waves-per-(sequence, head) form of the prompt steps (another summation order: the MODE picks it, never the batch size)
+int launch_attention_row(const half_t* qkv, const half_t* qrows, const int32_t* row_index, half_t* out, int B, int S, int H, int causal, hipStream_t s, int train = 0);
 int launch_gather_rows(const half_t* x, const int32_t* row_index, int row_stride, half_t* out, int n_rows, int d, hipStream_t s);
+// backward of launch_attention_row: o_rows / do_rows [B, H*64] (the forward's output rows and their gradient) -> the whole packed dqkv [B, S, 3, H*64]
+int launch_attention_row_bwd(const half_t* qkv, const half_t* o_rows, const half_t* do_rows, const int32_t* row_index, half_t* dqkv, int B, int S, int H, int causal,
+                             hipStream_t s);
 int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s);
 // shared_rows > 0: shared-prefix layout; kv_part [B, shared_rows, 2, H*64] f32 scratch for the per-sequence dK / dV of the shared keys
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s,
@@ -214,6 +218,9 @@ int launch_attention_bwd_tiled(const half_t* qkv, const half_t* o, const half_t*
 // backward row kernels (rowops_bwd.hip)
 int launch_layernorm_f16_from_f32(const float* x, const float* gamma, const float* beta, half_t* out, int M, int d, hipStream_t s);
 int launch_ln_bwd_add(const resid_t* x, const float* dln, int parts, int64_t part_stride, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s);
+// ln_bwd_add into a stream gradient that is rows_add[b] at row b * stride + index[b] and zero elsewhere (writes dx / dxh, reads neither)
+int launch_ln_bwd_init(const resid_t* x, const float* dln, int parts, int64_t part_stride, const float* gamma, const float* rows_add, const int32_t* index, int stride,
+                       float* dx, half_t* dxh, int M, int d, hipStream_t s);
 int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
                           int n, int d, hipStream_t s);
 int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* gamma, const float* scale, float* grad, int B, int S, int P, int d, hipStream_t s);

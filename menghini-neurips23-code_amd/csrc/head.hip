@@ -130,30 +130,55 @@ extern "C" int grip_cosine_head(const float* img_emb, const float* txt_emb, floa
 // ------------------------------------------------------------------------------------------------
 // Backward of logits = scale * ihat @ that^T (ihat, that = L2-normalised rows).
 //   d ihat = scale * dL @ that;  d img = (d ihat - ihat * <ihat, d ihat>) / ||img||      (same for txt with dL^T)
-// One wave per output row; `other` rows are normalised on the fly (n and c are small in training).
+// One workgroup (4 waves) per output row; wave w takes the `other` rows j = w (mod 4), two at a time (independent loads and wave
+// reductions in flight), normalising them on the fly (n and c are small in training); the four partial rows meet in LDS and wave 0
+// adds them in wave order and projects.  (Until r03 one wave walked all of a row's `other` rows: 45 dependent trips = 41 us of a VPT
+// step for a 16 x 45 head.)
 __global__ __launch_bounds__(256) void cosine_head_bwd_kernel(const float* __restrict__ self, const float* __restrict__ other, float scale,
                                                               int n_self, int n_other, int e, const float* __restrict__ dl, int transposed,
                                                               int ld_dl, float* __restrict__ grad) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_self) return;
+    __shared__ f32x4 part[3][64 * HEAD_MAX_EV];      // partial rows of waves 1..3 (wave 0 keeps its own in registers)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x;
     const int e4 = e >> 2;
     f32x4 acc[HEAD_MAX_EV];
 #pragma unroll
     for (int i = 0; i < HEAD_MAX_EV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < n_other; ++j) {
-        const f32x4* o = (const f32x4*)(other + (size_t)j * e);
-        f32x4 v[HEAD_MAX_EV];
-        float q = 0.f;
+    auto dlv = [&](int j) { return transposed ? dl[(size_t)j * ld_dl + row] : dl[(size_t)row * ld_dl + j]; };
+    for (int j0 = wave; j0 < n_other; j0 += 8) {
+        const int j1 = j0 + 4;
+        const bool two = j1 < n_other;
+        const f32x4* o0 = (const f32x4*)(other + (size_t)j0 * e);
+        const f32x4* o1 = (const f32x4*)(other + (size_t)(two ? j1 : j0) * e);
+        f32x4 v0[HEAD_MAX_EV], v1[HEAD_MAX_EV];
+        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
         for (int i = 0; i < HEAD_MAX_EV; ++i)
-            if (lane + 64 * i < e4) { v[i] = o[lane + 64 * i]; q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3]; }
-        const float inv = 1.0f / sqrtf(wsum(q));
-        const float g = scale * (transposed ? dl[(size_t)j * ld_dl + row] : dl[(size_t)row * ld_dl + j]) * inv;
+            if (lane + 64 * i < e4) {
+                v0[i] = o0[lane + 64 * i];
+                v1[i] = o1[lane + 64 * i];
+                q0 += v0[i][0] * v0[i][0] + v0[i][1] * v0[i][1] + v0[i][2] * v0[i][2] + v0[i][3] * v0[i][3];
+                q1 += v1[i][0] * v1[i][0] + v1[i][1] * v1[i][1] + v1[i][2] * v1[i][2] + v1[i][3] * v1[i][3];
+            }
+        const float g0 = scale * dlv(j0) / sqrtf(wsum(q0));
+        const float g1 = two ? scale * dlv(j1) / sqrtf(wsum(q1)) : 0.f;
 #pragma unroll
         for (int i = 0; i < HEAD_MAX_EV; ++i)
-            if (lane + 64 * i < e4) acc[i] += v[i] * g;
+            if (lane + 64 * i < e4) {
+                acc[i] += v0[i] * g0;
+                acc[i] += v1[i] * g1;
+            }
     }
+    if (wave != 0) {
+#pragma unroll
+        for (int i = 0; i < HEAD_MAX_EV; ++i)
+            if (lane + 64 * i < e4) part[wave - 1][lane + 64 * i] = acc[i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < HEAD_MAX_EV; ++i)
+        if (lane + 64 * i < e4) acc[i] = ((acc[i] + part[0][lane + 64 * i]) + part[1][lane + 64 * i]) + part[2][lane + 64 * i];
     const f32x4* x = (const f32x4*)(self + (size_t)row * e);
     f32x4 xs[HEAD_MAX_EV];
     float q = 0.f, dot = 0.f;
@@ -180,9 +205,9 @@ extern "C" int grip_cosine_head_backward(const float* img_emb, const float* txt_
     GRIP_REQUIRE(n > 0 && c > 0 && e % 4 == 0 && e <= 256 * HEAD_MAX_EV, "cosine_head_backward: unsupported shape");
     hipStream_t s = (hipStream_t)stream;
     if (grad_img)
-        hipLaunchKernelGGL(cosine_head_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, s, img_emb, txt_emb, scale, n, c, e, grad_logits, 0, c, grad_img);
+        hipLaunchKernelGGL(cosine_head_bwd_kernel, dim3(n), dim3(256), 0, s, img_emb, txt_emb, scale, n, c, e, grad_logits, 0, c, grad_img);
     if (grad_txt)
-        hipLaunchKernelGGL(cosine_head_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, s, txt_emb, img_emb, scale, c, n, e, grad_logits, 1, c, grad_txt);
+        hipLaunchKernelGGL(cosine_head_bwd_kernel, dim3(c), dim3(256), 0, s, txt_emb, img_emb, scale, c, n, e, grad_logits, 1, c, grad_txt);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -70,6 +70,34 @@ __global__ __launch_bounds__(256) void ln_bwd_add_kernel(const resid_t* __restri
         }
 }
 
+// dx[r] = LNbwd(sum_p dln[p][r]; x[r]) + (r is the read row of its sequence ? rows_add[sequence] : 0);  dxh[r] = f16(dx[r]).
+// The ln_1 backward of the LAST block when that block ran for the read rows only (csrc/tower.hip): the stream gradient entering the
+// block is zero except at row b * stride + index[b] of sequence b, where it is rows_add[b] -- no zero fill, no scatter.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_init_kernel(const resid_t* __restrict__ x, const float* __restrict__ dln, const float* __restrict__ gamma,
+                                                          const float* __restrict__ rows_add, const int32_t* __restrict__ index, int stride,
+                                                          float* __restrict__ dx, half_t* __restrict__ dxh, int M, int d, int parts, size_t part_stride4) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int d4 = d >> 2;
+    f32x4 g[NV];
+    ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g, parts, part_stride4);
+    const int b = row / stride;
+    const bool read = row - b * stride == (index ? index[b] : 0);
+    const f32x4* add = (const f32x4*)(rows_add + (size_t)b * d);
+    f32x4* o = (f32x4*)(dx + (size_t)row * d);
+    half4* oh = (half4*)(dxh + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            f32x4 v = g[i];
+            if (read) v += add[lane + 64 * i];
+            o[lane + 64 * i] = v;
+            oh[lane + 64 * i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+}
+
 // Final LayerNorm (ln_post on the CLS row / ln_final on the EOT row): dx[row_b] = LNbwd(dy[b]; x[row_b]),
 // row_b = b * stride + (index ? index[b] : 0).  dx / dxh were zero-filled before.
 template <int NV>
@@ -94,24 +122,37 @@ __global__ __launch_bounds__(256) void ln_bwd_scatter_kernel(const resid_t* __re
 }
 
 // Visual prompt slice through ln_pre: grad_prefix[s] = inv_scale * sum_b LNbwd(dx[b*S + 1 + s]; prefix[s]).
-// One wave per prompt token, fixed summation order over the batch (deterministic).
+// One workgroup of 8 waves per prompt token: wave w sums the images b = w (mod 8) in order, the eight partial rows meet in LDS and wave 0
+// adds them in wave order (deterministic).  (Until r03 one wave walked the whole batch: 16 dependent LayerNorm-backward rows = 32 us.)
 template <int NV>
-__global__ __launch_bounds__(256) void vit_prefix_grad_kernel(const float* __restrict__ dx, const float* __restrict__ prefix, const float* __restrict__ gamma,
+__global__ __launch_bounds__(512) void vit_prefix_grad_kernel(const float* __restrict__ dx, const float* __restrict__ prefix, const float* __restrict__ gamma,
                                                               const float* __restrict__ scale, float* __restrict__ grad, int B, int S, int P, int d) {
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= P) return;
+    __shared__ f32x4 part[7][64 * NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x;
     const int d4 = d >> 2;
     f32x4 acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) {
+    for (int b = wave; b < B; b += 8) {
         f32x4 g[NV];
         ln_bwd_row<NV>(prefix + (size_t)s * d, (const f32x4*)(dx + ((size_t)b * S + 1 + s) * d), (const f32x4*)gamma, lane, d4, d, g);
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (lane + 64 * i < d4) acc[i] += g[i];
     }
+    if (wave != 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < d4) part[wave - 1][lane + 64 * i] = acc[i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 7; ++w)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < d4) acc[i] += part[w][lane + 64 * i];
     const float inv = scale[1];
     f32x4* o = (f32x4*)(grad + (size_t)s * d);
 #pragma unroll
@@ -208,6 +249,14 @@ int launch_ln_bwd_add(const resid_t* x, const float* dln, int parts, int64_t par
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
+int launch_ln_bwd_init(const resid_t* x, const float* dln, int parts, int64_t part_stride, const float* gamma, const float* rows_add, const int32_t* index, int stride,
+                       float* dx, half_t* dxh, int M, int d, hipStream_t s) {
+    GRIP_REQUIRE(parts >= 1 && part_stride % 4 == 0 && stride >= 1, "ln_bwd_init: bad layout (parts=%d stride=%lld rows per sequence=%d)", parts, (long long)part_stride, stride);
+    DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_init_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, rows_add, index, stride, dx, dxh, M, d, parts,
+                                        (size_t)(part_stride / 4)));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
 int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
                           int n, int d, hipStream_t s) {
     DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_scatter_kernel<NV>, dim3((n + 3) / 4), dim3(256), 0, s, x, dy, index, stride, gamma, dx, dxh, n, d));
@@ -215,7 +264,7 @@ int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* inde
     return GRIP_OK;
 }
 int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* gamma, const float* scale, float* grad, int B, int S, int P, int d, hipStream_t s) {
-    DISPATCH_NV_B(d, hipLaunchKernelGGL(vit_prefix_grad_kernel<NV>, dim3((P + 3) / 4), dim3(256), 0, s, dx, prefix, gamma, scale, grad, B, S, P, d));
+    DISPATCH_NV_B(d, hipLaunchKernelGGL(vit_prefix_grad_kernel<NV>, dim3(P), dim3(512), 0, s, dx, prefix, gamma, scale, grad, B, S, P, d));
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -163,10 +163,22 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     half_t* cls16 = nullptr;   // [round_up(batch,128), d]
     half_t* patches = nullptr; // alias of h
     float* patch_out = nullptr;// alias of qkv
-    half_t* row_x = nullptr;   // compact last-block buffers (inference, f16 towers): [Bp, d] stream rows, [Bp, d] attention rows,
+    half_t* row_x = nullptr;   // compact last-block buffers (f16 towers): [Bp, d] stream rows, [Bp, d] attention rows,
     half_t* row_att = nullptr; // [Bp, d] LayerNorm output, [Bp, 4d] MLP hidden
     half_t* row_xn = nullptr;
     half_t* row_h = nullptr;
+    // ... and, when a TRAIN-mode forward runs its last block for the read rows only (rows_last): what that block saves for its backward
+    // and the backward's own compact scratch
+    int rows_last = 0;
+    int ks_row = 1;            // split factor of the compact fc input-gradient GEMM
+    half_t* row_hpre = nullptr;   // [Bp, 4d] pre-activations
+    resid_t* row_xmid = nullptr;  // [Bp, d] stream rows after the attention branch
+    resid_t* row_xout = nullptr;  // [Bp, d] stream rows after the block (what ln_post / ln_final reads)
+    float* drow = nullptr;        // [Bp, d] f32 gradient of those stream rows
+    half_t* drow_h = nullptr;     // ... its f16 copy (GEMM operand)
+    half_t* row_dh = nullptr;     // [Bp, 4d]
+    float* row_dln = nullptr;     // [ks_row][Bp, d]
+    half_t* row_datt = nullptr;   // [Bp, d]
     float* stat_part = nullptr;// [d/64, M, 2] partial row sums emitted by the residual GEMM epilogues (f16 towers)
     float* rowstat = nullptr;  // [Mp, 2] (mean, rstd) of the residual stream's rows, consumed by the LayerNorm-folded GEMMs
     // train-mode saves, one per layer (x_in has layers+1 entries)
@@ -215,6 +227,12 @@ struct grip_tower {
     std::map<void*, TrainState> pending;
 };
 
+// GRIP_LAST_BLOCK_FULL=1: the last block runs for every row, as the reference's does (A/B; the tests hold the two paths equal)
+static bool last_block_full() {
+    static const bool full = getenv("GRIP_LAST_BLOCK_FULL") && atoi(getenv("GRIP_LAST_BLOCK_FULL")) != 0;
+    return full;
+}
+
 static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w, int seq_len = 0, int shared = 0) {
     const grip_dims& D = t->D;
     GRIP_REQUIRE(batch > 0 && P >= 0 && P <= D.max_prefix, "batch must be positive and 0 <= n_prefix <= max_prefix (batch=%d n_prefix=%d max=%d)", batch, P, D.max_prefix);
@@ -239,11 +257,23 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * es); w.att = (half_t*)take(w.Mp * d * es); }
     w.h = (half_t*)take(w.Mp * 4 * d * es);
     w.cls16 = (half_t*)take(Bp * d * es);
-    if (!t->f32 && !train) {
+    w.rows_last = train && !t->f32 && !shared && !last_block_full();
+    if (!t->f32 && (!train || w.rows_last)) {
         w.row_x = (half_t*)take(Bp * d * 2);
         w.row_att = (half_t*)take(Bp * d * 2);
         w.row_xn = (half_t*)take(Bp * d * 2);
         w.row_h = (half_t*)take(Bp * 4 * d * 2);
+    }
+    if (w.rows_last) {
+        w.row_hpre = (half_t*)take(Bp * 4 * d * 2);
+        w.row_xmid = (resid_t*)take(Bp * d * sizeof(resid_t));
+        w.row_xout = (resid_t*)take(Bp * d * sizeof(resid_t));
+        w.drow = (float*)take(Bp * d * 4);
+        w.drow_h = (half_t*)take(Bp * d * 2);
+        w.row_dh = (half_t*)take(Bp * 4 * d * 2);
+        w.ks_row = gemm_pick_ksplit(batch, d, 4 * d);
+        w.row_dln = (float*)take(Bp * d * 4 * (size_t)w.ks_row);
+        w.row_datt = (half_t*)take(Bp * d * 2);
     }
     if (!t->f32) {
         w.stat_part = (float*)take(w.Mp * (d / 64) * 2 * sizeof(float));
@@ -370,8 +400,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
     // every row but its attention output, out-proj, LayerNorm and MLP for that row alone (M = batch instead of batch x S):
     // 2.2 of the block's 2.9 GFLOP per ViT-B/16 image are never issued, the embedding is unchanged.  GRIP_LAST_BLOCK_FULL=1
     // computes the whole block as the reference does (A/B; the tests hold the two paths equal).
-    static const bool last_full = getenv("GRIP_LAST_BLOCK_FULL") && atoi(getenv("GRIP_LAST_BLOCK_FULL")) != 0;
-    const bool rows_only = fold && !last_full && !w.Ps;
+    const bool rows_only = fold && !last_block_full() && !w.Ps;
     *compact = false;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
@@ -400,6 +429,33 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             a.A = w.row_h; a.W = t->w16 + lw.proj_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
             RUN(launch_gemm(EPI_BIAS_RESID, a, s));
             x = w.row_x;
+            *compact = true;
+            break;
+        }
+        if (last && w.rows_last) {
+            // The same in TRAIN mode (prompt steps; plain row layout): the block's K, V and -- one GEMM, saved for the backward -- Q of every
+            // row, then attention output, out-proj, ln_2 and the MLP for the read rows alone, each saving what its backward needs in compact
+            // [batch, .] buffers.  The backward (run_blocks_backward) mirrors it: 0.14 ms of a 3.15-ms VPT step.
+            const int64_t Bp = round_up64(w.batch, 256);
+            half_t* qkv = w.qkv_l[(size_t)l];
+            GemmArgs a{};
+            RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, 0, w.M, d, s));
+            a.rot_rows = 1;
+            a.A = w.xn; a.W = t->w16 + lw.in_w; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
+            RUN(launch_gemm(EPI_BIAS_F16, a, s));
+            RUN(launch_attention_row(qkv, nullptr, read_rows, w.row_att, w.batch, w.S, H, causal, s, /*train=*/1));
+            RUN(launch_gather_rows(x, read_rows, w.S, w.row_x, w.batch, d, s));
+            a = GemmArgs{};
+            a.A = w.row_att; a.W = t->w16 + lw.out_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = w.row_x; a.out = w.row_xmid; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_RESID, a, s));
+            RUN(launch_layernorm_f16(w.row_xmid, F + lw.ln2_g, F + lw.ln2_b, w.row_xn, 0, w.batch, d, s));
+            a = GemmArgs{};
+            a.A = w.row_xn; a.W = t->w16 + lw.fc_w; a.M = w.batch; a.m_pad = Bp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.row_h; a.out2 = w.row_hpre; a.ldc = 4 * d;
+            RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
+            a = GemmArgs{};
+            a.A = w.row_h; a.W = t->w16 + lw.proj_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = w.row_xmid; a.out = w.row_xout; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_RESID, a, s));
+            x = w.row_xout;
             *compact = true;
             break;
         }
@@ -585,13 +641,39 @@ extern "C" int grip_debug_layernorm(const float* x, const float* gamma, const fl
 // ---------------------------------------------------------------------------------------------- backward
 // Input-gradient chain of one tower down to its prompt slice.  Enters with dx / dxh holding the
 // (loss-scaled) gradient w.r.t. the final residual stream, leaves with dx = gradient w.r.t. x0.
-static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, hipStream_t s) {
+static int run_blocks_backward(grip_tower* t, Workspace& w, int causal, const int32_t* read_rows, hipStream_t s) {
     const int d = t->D.width, H = t->D.heads;
     const half_t* W = t->w16;
     const float* F = t->w32;
     const int64_t part = (int64_t)w.Mp * d;       // floats between split-K partial buffers in w.dln
     for (int l = t->D.layers - 1; l >= 0; --l) {
         const LayerW& lw = t->L.layer[(size_t)l];
+        if (l + 1 == t->D.layers && w.rows_last) {
+            // the last block ran for the read rows only (run_blocks): enters with drow / drow_h = the gradient of those stream rows
+            const int64_t Bp = round_up64(w.batch, 256);
+            const int64_t rpart = Bp * d;
+            GemmArgs a{};
+            a.A = w.drow_h; a.W = W + lw.proj_wT; a.M = w.batch; a.m_pad = Bp; a.N = 4 * d; a.K = d; a.aux = w.row_hpre; a.out = w.row_dh; a.ldc = 4 * d;
+            RUN(launch_gemm(EPI_GELUGRAD_F16, a, s));
+            a = GemmArgs{};
+            a.A = w.row_dh; a.W = W + lw.fc_wT; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.out = w.row_dln; a.ldc = d;
+            a.ksplit = w.ks_row; a.split_stride = rpart;
+            RUN(launch_gemm(EPI_F32, a, s));
+            RUN(launch_ln_bwd_add(w.row_xmid, w.row_dln, w.ks_row, rpart, F + lw.ln2_g, w.drow, w.drow_h, w.batch, d, s));
+            a = GemmArgs{};
+            a.A = w.drow_h; a.W = W + lw.out_wT; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.out = w.row_datt; a.ldc = d;
+            RUN(launch_gemm(EPI_F16, a, s));
+            // d(q, k, v) of every row from the read rows' d(attention output): rank-one in (q, dO) per head
+            RUN(launch_attention_row_bwd(w.qkv_l[(size_t)l], w.row_att, w.row_datt, read_rows, w.dqkv, w.batch, w.S, H, causal, s));
+            a = GemmArgs{};
+            a.rot_rows = 1;
+            a.A = w.dqkv; a.W = W + lw.in_wT; a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 3 * d; a.out = w.dln; a.ldc = d;
+            a.ksplit = w.ks_in; a.split_stride = part;
+            RUN(launch_gemm(EPI_F32, a, s));
+            // the stream gradient entering the block: drow at the read rows, zero elsewhere (no fill, no scatter)
+            RUN(launch_ln_bwd_init(w.x_in[(size_t)l], w.dln, w.ks_in, part, F + lw.ln1_g, w.drow, read_rows, w.S, w.dx, w.dxh, w.M, d, s));
+            continue;
+        }
         GemmArgs a{};
         a.rot_rows = 1;           // (backward GEMMs: train mode by definition)
         // d(pre-activation) = (dx @ W_proj) * quickgelu'(h_pre)
@@ -626,6 +708,8 @@ static int backward_head_of_tower(grip_tower* t, Workspace& w, const float* grad
     GemmArgs a{};
     a.A = w.gemb16; a.W = t->w16 + t->L.proj; a.M = w.batch; a.N = d; a.K = D.embed_dim; a.out = w.dcls; a.ldc = d;
     RUN(launch_gemm(EPI_F32, a, s));
+    if (w.rows_last)      // compact: the final stream exists for the read rows only (run_blocks)
+        return launch_ln_bwd_scatter(w.row_xout, w.dcls, nullptr, 1, t->w32 + t->L.lnpost_g, w.drow, w.drow_h, w.batch, d, s);
     GRIP_CHECK_HIP(hipMemsetAsync(w.dx, 0, (size_t)w.M * d * 4, s));
     GRIP_CHECK_HIP(hipMemsetAsync(w.dxh, 0, (size_t)w.M * d * 2, s));
     // row of (sequence b, position index[b]): b * rs + index[b] in either layout (shared-prefix: Ps + b*(S-Ps) + index - Ps)
@@ -670,7 +754,7 @@ extern "C" int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, co
         GRIP_REQUIRE(w.P > 0, "vit_backward_prefix: forward had no prompt tokens");
         hipStream_t s = (hipStream_t)stream;
         RUN(backward_head_of_tower(t, w, grad_emb, nullptr, s));
-        RUN(run_blocks_backward(t, w, 0, s));
+        RUN(run_blocks_backward(t, w, 0, nullptr, s));
         RUN(launch_vit_prefix_grad(w.dx, prefix, t->w32 + t->L.lnpre_g, w.scale, grad_prefix, w.batch, w.S, w.P, t->D.width, s));
         return GRIP_OK;
     } catch (...) { grip_set_error("vit_backward_prefix: exception"); return GRIP_ERR_ARG; }
@@ -686,7 +770,7 @@ extern "C" int grip_text_backward_prefix(grip_tower* t, const float* grad_emb, f
         GRIP_REQUIRE(w.P > 0, "text_backward_prefix: forward had no prompt tokens");
         hipStream_t s = (hipStream_t)stream;
         RUN(backward_head_of_tower(t, w, grad_emb, st.eot, s));
-        RUN(run_blocks_backward(t, w, 1, s));
+        RUN(run_blocks_backward(t, w, 1, st.eot, s));
         if (w.Ps)   // shared-prefix layout: every class's share already met in the shared rows (rows 1 .. P)
             RUN(launch_text_prefix_grad(w.dx, w.scale, grad_prefix, 1, w.S, w.P, 1, t->D.width, s));
         else

@@ -250,6 +250,17 @@ for name, res in (("small", 64), ("ViT-B/16", 224)):
     tok = clip.tokenize(["a photo of a forest", "x x river bank", "highway"]).cuda()
     with torch.no_grad():
         out[name] = [m.encode_image(x).cpu(), m.visual(x, p).cpu(), m.encode_text(tok).cpu()]
+    # train mode (r03): forward + prompt gradients through the vision tower and through the text tower with one context per class
+    # (the plain row layout; the shared-prefix layout keeps the full block)
+    from grip_amd.engine import TextPrefixFn, VitPrefixFn
+    a = p.clone().requires_grad_(True)
+    e = VitPrefixFn.apply(m.visual.tower, x, a)
+    (e * torch.from_numpy(rng.normal(9, rng.stream_id("lb.g." + name), tuple(e.shape))).cuda()).sum().backward()
+    tp = torch.from_numpy(rng.normal(9, rng.stream_id("lb.tp." + name), (3, 2, m.text_tower.width), 0.0, 0.05)).cuda().requires_grad_(True)
+    tok2 = clip.tokenize(["X X a forest", "X X river bank today", "X X highway"]).cuda()
+    et = TextPrefixFn.apply(m.text_tower, tok2, tp)
+    (et * torch.from_numpy(rng.normal(9, rng.stream_id("lb.gt." + name), tuple(et.shape))).cuda()).sum().backward()
+    out[name + " train"] = [e.detach().cpu(), a.grad.cpu(), et.detach().cpu(), tp.grad.cpu()]
 torch.save(out, os.environ["GRIP_OUT"])
 ''')
     res = {}
@@ -259,7 +270,8 @@ torch.save(out, os.environ["GRIP_OUT"])
         assert r.returncode == 0, r.stderr[-2000:]
         res[full] = torch.load(str(tmp_path / f"o{full}.pt"))
     for name in res["0"]:
-        for a, b in zip(res["0"][name], res["1"][name]):
-            cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
-            assert (1 - cos).max().item() <= 2e-6 and ((a - b).norm() / b.norm()).item() <= 2e-3, (name, (1 - cos).max().item())
+        for i, (a, b) in enumerate(zip(res["0"][name], res["1"][name])):
+            cos = torch.nn.functional.cosine_similarity(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), dim=-1)
+            grad = name.endswith("train") and i in (1, 3)       # prompt gradients: f16 gradient stream, one more rounding per block
+            assert (1 - cos).max().item() <= (2e-4 if grad else 2e-6) and ((a - b).norm() / b.norm()).item() <= (1e-2 if grad else 2e-3), (name, i, (1 - cos).max().item())
             assert not torch.equal(a, b)        # the two paths really are different code

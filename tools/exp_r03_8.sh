@@ -1,10 +1,11 @@
 #!/bin/bash
-# per-kernel, per-grid-size times of the VPT step in situ (all kernels), this tree
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
+cd $R
+python -m pytest tests/test_gpu_towers.py tests/test_gpu_backward.py tests/test_gpu_strategies.py tests/test_gpu_determinism.py tests/test_gpu_kernels.py -q -m gpu -x 2>&1 | grep -E "passed|failed|rror|FAILED|assert|ERROR" | tail -15 > $R/gpurun_out/exp8.log
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/vp_rows; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/vp_rows -o r -- python $R/tools/vpt_loop.py > /dev/null 2>&1
-python3 - /tmp/vp_rows > $R/gpurun_out/exp7.log <<'PY'
+rm -rf /tmp/up; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/up -o r -- python $R/tools/upt_loop.py > /tmp/upt.out 2>&1; tail -3 /tmp/upt.out >> $R/gpurun_out/exp8.log
+python3 - /tmp/up >> $R/gpurun_out/exp8.log <<'PY'
 import csv, sys, collections, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: [0, 0.0])
@@ -19,4 +20,4 @@ for k, (n, s) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
     tot += s / 30
 print("total per step", round(tot, 1))
 PY
-cat $R/gpurun_out/exp7.log
+head -70 $R/gpurun_out/exp8.log
