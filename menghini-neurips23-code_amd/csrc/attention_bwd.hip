@@ -178,20 +178,31 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     __syncthreads();
     // ------------------------------------------------------------------ phase 2: dK, dV per key tile
     const int n_kt = (S + 15) >> 4;
-    for (int kt = wave; kt < n_kt; kt += NWB) {
+    // A wave takes TWO adjacent key tiles at a time (r03): the recomputed S / dP of a query step feed two independent chains (MFMA ->
+    // exp / dS -> MFMA) that the scheduler interleaves, and the query-side operands (the Q / dO rows from L2, the transposed Q / dO
+    // fragments from LDS) are fetched once for both.  At S = 213 the 14 key tiles are one round of seven waves instead of two rounds of
+    // eight (the second one three quarters empty); a tile past the last one works on zero rows and stores nothing.
+    constexpr int NT = 2;
+    for (int kt0 = wave * NT; kt0 < n_kt; kt0 += NWB * NT) {
         asm volatile("" ::: "memory");
-        const int kvrow = kt * 16 + li;   // this lane's key (B-operand row / output column)
-        half8 kf[2], vf[2];
+        int kvrow[NT];            // this lane's key (B-operand row / output column) in either tile
+        half8 kf[NT][2], vf[NT][2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int sw = ((kk * 4 + lg) ^ (lane & 7)) * 8;
-            kf[kk] = *(const half8*)(Ks + kvrow * 64 + sw);
-            vf[kk] = *(const half8*)(Vs + kvrow * 64 + sw);
+        for (int u = 0; u < NT; ++u) {
+            kvrow[u] = (kt0 + u) * 16 + li;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int sw = ((kk * 4 + lg) ^ (lane & 7)) * 8;
+                kf[u][kk] = *(const half8*)(Ks + kvrow[u] * 64 + sw);      // (rows S .. SP - 1 of Ks / Vs are zero)
+                vf[u][kk] = *(const half8*)(Vs + kvrow[u] * 64 + sw);
+            }
         }
-        f32x4 dk[4], dv[4];
+        f32x4 dk[NT][4], dv[NT][4];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) { dk[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        const int c_begin = CAUSAL ? (kt * 16) / 32 : 0;   // queries before the key tile see none of its keys
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) { dk[u][nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[u][nf] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        const int c_begin = CAUSAL ? (kt0 * 16) / 32 : 0;   // queries before the first key tile see none of these keys
         // A operands of the recomputed S and dP: query rows of Q and dO straight from HBM / L2 (row = q0 + li); the LDS holds the
         // transposed images only.  The rows of 16-query step `it + 1` are requested before step `it` is computed (r03: the loads of a
         // step used to be issued at its top, a full L2 round trip exposed per step and wave -- 14 steps per key tile at S = 213).
@@ -208,59 +219,75 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
         load_rows(2 * c_begin, q_nx, do_nx);
 #pragma unroll 1
         for (int c = c_begin; c < KVC; ++c) {     // not unrolled: KVC copies of this body cost > 256 VGPRs
-            half8 pf, sf;
+            half8 pf[NT], sf[NT];
 #pragma unroll
             for (int half_i = 0; half_i < 2; ++half_i) {
                 const int q0 = c * 32 + half_i * 16;
                 half8 qa_f[2] = {q_nx[0], q_nx[1]}, do_f[2] = {do_nx[0], do_nx[1]};
                 if (2 * c + half_i + 1 < 2 * KVC) load_rows(2 * c + half_i + 1, q_nx, do_nx);
-                f32x4 s_acc = {0.f, 0.f, 0.f, 0.f}, p_acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 s_acc[NT], p_acc[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) { s_acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; p_acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
                 if (GRIP_ATTNB_PRIO & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     qa_f[kk] *= (half_t)0.125f;
-                    s_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa_f[kk], kf[kk], s_acc, 0, 0, 0);   // S[q][kv]
-                    p_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(do_f[kk], vf[kk], p_acc, 0, 0, 0);   // dP[q][kv]
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        s_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa_f[kk], kf[u][kk], s_acc[u], 0, 0, 0);   // S[q][kv]
+                        p_acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(do_f[kk], vf[u][kk], p_acc[u], 0, 0, 0);   // dP[q][kv]
+                    }
                 }
                 if (GRIP_ATTNB_PRIO & 4) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + lg * 4 + r;
-                    float p = 0.f, ds = 0.f;   // padding rows carry no statistics: keep them exactly zero
-                    if (q < S && q >= q_min && kvrow < S && !(CAUSAL && kvrow > q)) {
-                        p = __expf(s_acc[r] - st_m[q]) * st_il[q];
-                        ds = p * (p_acc[r] - st_d[q]);
+                    const bool qok = q < S && q >= q_min;
+                    const float mq = st_m[q < SP ? q : SP - 1], ilq = st_il[q < SP ? q : SP - 1], dq_ = st_d[q < SP ? q : SP - 1];
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        float p = 0.f, ds = 0.f;   // padding rows carry no statistics: keep them exactly zero
+                        if (qok && kvrow[u] < S && !(CAUSAL && kvrow[u] > q)) {
+                            p = __expf(s_acc[u][r] - mq) * ilq;
+                            ds = p * (p_acc[u][r] - dq_);
+                        }
+                        pf[u][half_i * 4 + r] = (half_t)p;
+                        sf[u][half_i * 4 + r] = (half_t)ds;
                     }
-                    pf[half_i * 4 + r] = (half_t)p;
-                    sf[half_i * 4 + r] = (half_t)ds;
                 }
             }
             if (GRIP_ATTNB_PRIO & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
                 const half8 dof = *(const half8*)(T1 + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
-                dv[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dof, pf, dv[nf], 0, 0, 0);   // dV^T[dh][kv]
                 const half8 qtf = *(const half8*)(T0 + (c * 4 + nf) * 512 + (lg * 16 + (li ^ lg)) * 8);
-                dk[nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, sf, dk[nf], 0, 0, 0);   // dK^T[dh][kv]
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    dv[u][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dof, pf[u], dv[u][nf], 0, 0, 0);   // dV^T[dh][kv]
+                    dk[u][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, sf[u], dk[u][nf], 0, 0, 0);   // dK^T[dh][kv]
+                }
             }
             if (GRIP_ATTNB_PRIO & 8) __builtin_amdgcn_s_setprio(0);
         }
-        if (kvrow < Ps) {
-            // a shared key: this sequence's share goes to kv_part [b][key][dK | dV][D] in f32; attn_shared_kv_reduce adds the
-            // shares of all sequences in index order
-            float* pp = kv_part + (((size_t)b * Ps + kvrow) * 2) * D + h * 64 + lg * 4;
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                *(f32x4*)(pp + nf * 16) = dk[nf];
-                *(f32x4*)(pp + D + nf * 16) = dv[nf];
-            }
-        } else if (kvrow < S) {
-            half_t* kp = dbase + R(kvrow) * ld + D + lg * 4;
-            half_t* vp = kp + D;
+        for (int u = 0; u < NT; ++u) {
+            if (kvrow[u] < Ps) {
+                // a shared key: this sequence's share goes to kv_part [b][key][dK | dV][D] in f32; attn_shared_kv_reduce adds the
+                // shares of all sequences in index order
+                float* pp = kv_part + (((size_t)b * Ps + kvrow[u]) * 2) * D + h * 64 + lg * 4;
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                *(half4*)(kp + nf * 16) = (half4){(half_t)dk[nf][0], (half_t)dk[nf][1], (half_t)dk[nf][2], (half_t)dk[nf][3]};
-                *(half4*)(vp + nf * 16) = (half4){(half_t)dv[nf][0], (half_t)dv[nf][1], (half_t)dv[nf][2], (half_t)dv[nf][3]};
+                for (int nf = 0; nf < 4; ++nf) {
+                    *(f32x4*)(pp + nf * 16) = dk[u][nf];
+                    *(f32x4*)(pp + D + nf * 16) = dv[u][nf];
+                }
+            } else if (kvrow[u] < S) {
+                half_t* kp = dbase + R(kvrow[u]) * ld + D + lg * 4;
+                half_t* vp = kp + D;
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) {
+                    *(half4*)(kp + nf * 16) = (half4){(half_t)dk[u][nf][0], (half_t)dk[u][nf][1], (half_t)dk[u][nf][2], (half_t)dk[u][nf][3]};
+                    *(half4*)(vp + nf * 16) = (half4){(half_t)dv[u][nf][0], (half_t)dv[u][nf][1], (half_t)dv[u][nf][2], (half_t)dv[u][nf][3]};
+                }
             }
         }
     }
