@@ -1700,6 +1700,19 @@ int gemm_pick_ksplit(int M, int N, int K) {
     const int nk = K / BK;
     if (force >= 1) return nk % force == 0 ? force : 1;
     if (tiles >= 512) return 1;
+    // More 64-row tiles than CUs (the image tower's input-gradient GEMMs: M = 3 408, N = 768 -> 324): 128-row tiles instead, split so that
+    // about two of their 64-KiB workgroups share a CU -- the largest factor with <= 512 workgroups and >= 8 K tiles each.  VPT step in situ
+    // (tools/exp_r03_5.sh): 2 x 324 workgroups of 64x128 23.2 us, 2 x 162 of 128x128 23.2 us, 3 x 162 of 128x128 20.0 us (the third partial
+    // costs ln_bwd_add 1.5 us: 10.0 -> 11.5).
+    {
+        const int64_t t128 = (int64_t)((M + 127) / 128) * (N / BN);
+        if (tiles > 256 && t128 <= 256) {
+            int f128 = 1;
+            for (int f : {2, 3, 4})
+                if (nk % f == 0 && nk / f >= 8 && t128 * f <= 512) f128 = f;
+            if (f128 > 1) return f128;
+        }
+    }
     int best = 1;
     for (int f : {2, 3, 4, 6, 8}) {
         if (nk % f || nk / f < 3) continue;
@@ -1835,7 +1848,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     if (ksplit > 1) {
         GRIP_REQUIRE(epi == EPI_F32 && (a.K / BK) % ksplit == 0 && a.split_stride >= (int64_t)a.M * a.ldc,
                      "gemm: split-K needs EPI_F32, (K/64) %% ksplit == 0 and a partial stride >= M*ldc (K=%d ksplit=%d)", a.K, ksplit);
-        if (variant != 1) variant = 4;
+        // 128-row tiles where gemm_pick_ksplit sized the split for them (more 64-row tiles than CUs: about two 128-row workgroups per CU)
+        const int64_t t64 = (int64_t)((a.M + 63) / 64) * (a.N / BN), t128 = (int64_t)((a.M + 127) / 128) * (a.N / BN);
+        if (a.variant == 0 && t64 > 256 && t128 * ksplit <= 512) variant = 1;
+        else if (variant != 1) variant = 4;
     }
     if (variant == 5 && epi == EPI_BIAS_RESID_STATS) variant = 6;   // the one-tile-per-workgroup 64-wide kernel has no registers left for the statistics
     *chosen = variant;

@@ -9,7 +9,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    if "gemm" in n:
+    if "gemm" in n or "ln_bwd_add" in n:
         k = (n.replace("void ", "").split("(")[0], r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", "?"), r.get("LDS_Block_Size", r.get("LDS_Block_Size_v", "?")))
         acc[k][0] += 1
         acc[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -22,7 +22,12 @@ PY
 }
 go() { tag=$1; shift; rm -rf /tmp/vp_$tag; env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/vp_$tag -o r -- python $R/tools/vpt_loop.py > /dev/null 2>&1; summ /tmp/vp_$tag $tag; }
 {
-for r in 0 1 2 3 5 7 11; do go rot$r GRIP_KROT_M=$r; done
-for r in 0 1 2 3 5 7; do go r128off_rot$r GRIP_GEMM_R128=0 GRIP_KROT_M=$r; done
+go base GRIP_LIB=$R/menghini-neurips23-code_amd/libgrip_prev.so
+go new X=1
 } > $R/gpurun_out/exp5.log 2>&1
-grep "total\|ringw_kernel<3, [35]\|ring_kernel<3, 3\|k64_kernel\|f16_kernel<0, 2>\|f16_kernel<1, 4>\|ring_kernel<4" $R/gpurun_out/exp5.log
+grep "total\|f16_kernel<0\|ln_bwd_add" $R/gpurun_out/exp5.log
+cd $R; python -m pytest tests/test_gpu_kernels.py tests/test_gpu_backward.py tests/test_gpu_towers.py tests/test_gpu_strategies.py -q -m gpu -x 2>&1 | grep -E "passed|failed|rror|FAILED|assert|ERROR" | tail -5
+for rep in 1 2; do
+echo "== prev"; GRIP_LIB=$R/menghini-neurips23-code_amd/libgrip_prev.so python tools/secondary_probe.py 1 2>&1 | grep vpt_step | cut -c1-420
+echo "== new"; python tools/secondary_probe.py 1 2>&1 | grep vpt_step | cut -c1-420
+done

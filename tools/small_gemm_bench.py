@@ -17,7 +17,8 @@ from grip_amd import native  # noqa: E402
 lib = native.lib()
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ROT = 256 if os.environ.get("ROT", "0") == "1" else 0      # bit 8 of the debug hook's variant: the train-mode launches' row-staggered K walks
+variant = (int(sys.argv[1]) if len(sys.argv) > 1 else 0) | ROT
 ONLY = os.environ.get("ONLY", "")
 SWEEP = os.environ.get("SWEEP", "0") == "1"      # also time every tile shape / split factor per line
 
@@ -69,7 +70,7 @@ for name, epi, M, N, K in SHAPES:
             for v in (1, 4):
                 for ks in (1, 2, 3, 4, 6, 8):
                     if (K // 64) % ks == 0:
-                        tt = bench(lambda: run(ks, v))
+                        tt = bench(lambda: run(ks, v | ROT))
                         extra += f" | v{v} ks{ks} {tt:.1f}"
     else:
         def run(v=variant):
@@ -78,8 +79,10 @@ for name, epi, M, N, K in SHAPES:
         t = bench(run)
         extra = ""
         if SWEEP:
-            for v in (1, 4, 3):
-                tt = bench(lambda: run(v))
+            for v in (1, 4, 3, 5, 8):
+                if v in (5, 8) and N % 256:
+                    continue
+                tt = bench(lambda: run(v | ROT))
                 extra += f" | v{v} {tt:.1f}"
     total[name.split()[0]] += t
     print(f"{name:18s} epi {epi} M={M} N={N} K={K}: {t:7.2f} us {2.0 * M * N * K / t / 1e6:6.0f} TF/s {extra}", flush=True)
