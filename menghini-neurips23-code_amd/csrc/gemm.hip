@@ -1826,7 +1826,7 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
             // ... unless the 64-row tiles outnumber the CUs while the 128-row ones do not: one round of 128-row tiles on dedicated loader
             // waves (gemm_ringw_kernel) beats a round and a bit of 64-row ones (M = 3 408, N = 768, K = 3 072: 25.6 us against 31)
             static const bool r128 = !(getenv("GRIP_GEMM_R128") && atoi(getenv("GRIP_GEMM_R128")) == 0);     // developer A/B
-            if (r128 && variant == 4 && a.ksplit <= 1 && tm128 * (a.N / 128) <= 256 && (int64_t)((a.M + 63) / 64) * (a.N / 128) > 256 && a.K >= 2 * BK) { best = 1.0; variant = 1; }
+            if (r128 && variant == 4 && a.ksplit <= 1 && tm128 * (a.N / 128) <= 256 && (int64_t)((a.M + 63) / 64) * (a.N / 128) > 256 && a.K > 12 * BK) { best = 1.0; variant = 1; }
         }
         if (can_big) {
             const double s3 = 0.93 * fill(tm256 * (a.N / 128), 512);

@@ -22,12 +22,7 @@ PY
 }
 go() { tag=$1; shift; rm -rf /tmp/vp_$tag; env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/vp_$tag -o r -- python $R/tools/vpt_loop.py > /dev/null 2>&1; summ /tmp/vp_$tag $tag; }
 {
-go base GRIP_LIB=$R/menghini-neurips23-code_amd/libgrip_prev.so
+go prev GRIP_LIB=$R/menghini-neurips23-code_amd/libgrip_prev.so
 go new X=1
 } > $R/gpurun_out/exp5.log 2>&1
-grep "total\|f16_kernel<0\|ln_bwd_add" $R/gpurun_out/exp5.log
-cd $R; python -m pytest tests/test_gpu_kernels.py tests/test_gpu_backward.py tests/test_gpu_towers.py tests/test_gpu_strategies.py -q -m gpu -x 2>&1 | grep -E "passed|failed|rror|FAILED|assert|ERROR" | tail -5
-for rep in 1 2; do
-echo "== prev"; GRIP_LIB=$R/menghini-neurips23-code_amd/libgrip_prev.so python tools/secondary_probe.py 1 2>&1 | grep vpt_step | cut -c1-420
-echo "== new"; python tools/secondary_probe.py 1 2>&1 | grep vpt_step | cut -c1-420
-done
+grep "total\|ring" $R/gpurun_out/exp5.log | grep -v "', '[0-9]\{4,5\}', '512'" 
