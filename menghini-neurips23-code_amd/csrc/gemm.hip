@@ -1179,6 +1179,100 @@ __global__ __launch_bounds__(NW * 64) void gemm_k64_kernel(GemmArgs g, int tiles
         epilogue_rows<EPI, RF, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc[h], (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * RF * 16, n0 + wc * WCOLS + h * 64, lane);
 }
 
+// ---- Developer prototype (r03): the 192x256 tile of gemm_k64_kernel with the stage feed on FOUR DEDICATED WAVES (12 waves per workgroup:
+// eight consumers of 96x64 -- 96 accumulator registers, ONE fragment set: three waves share a SIMD and 170 registers each -- and four
+// producers that issue the 56 DMA pieces of a stage and are the only ones to sit in the vector-memory issue stage).  Variant 9 of the
+// debug hook / GRIP_GEMM_BIG=9; one tile per workgroup.
+template <int EPI>
+__global__ __launch_bounds__(768) void gemm_k64w_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int RF = 6, BMT = 32 * RF, BNT = 256;
+    constexpr int STAGE = (BMT + BNT) * BK;       // halfs per stage
+    constexpr int PIECES = (BMT + BNT) / 8;       // 56
+    constexpr int GP = PIECES / 4;                // per producer wave
+    extern __shared__ __attribute__((aligned(16))) half_t lds2[];
+
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BMT, n0 = tn * BNT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = g.K / BK;    // >= 2 (launcher)
+    const int rot = (k_rot(tn, tiles_n, nk) + tm * g.rot_rows) % nk;
+    auto ks = [&](int k) { return k + rot < nk ? k + rot : k + rot - nk; };
+
+    if (wave >= 8) {
+        const int pw = wave - 8;
+        const int srow = lane >> 3;
+        const int schunk = (lane & 7) ^ srow;
+        const size_t K = (size_t)g.K;
+        const uint32_t lane_off = 2u * ((uint32_t)srow * (uint32_t)g.K + (uint32_t)(schunk * 8));
+        auto stage = [&](int buf, int kt) {
+#pragma unroll
+            for (int i = 0; i < GP; ++i) {
+                const int pc = pw * GP + i;                   // piece: rows pc * 8 .. + 7 of the (A then W) stage
+                const half_t* row = pc * 8 < BMT ? (const half_t*)g.A + (size_t)(m0 + pc * 8) * K : (const half_t*)g.W + (size_t)(n0 + pc * 8 - BMT) * K;
+                __builtin_amdgcn_global_load_lds((const AS1 void*)((const char*)(row + (size_t)kt * BK) + lane_off), (AS3 void*)(lds2 + buf * STAGE + pc * 8 * BK), 16, 0, 0);
+            }
+        };
+        stage(0, ks(0));
+        stage(1, ks(1));
+        wait_vmcnt<GP>();
+        __builtin_amdgcn_s_barrier();                 // stage 0 landed
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<0>();                          // stage kt + 1 landed
+            __builtin_amdgcn_s_barrier();             // ... and every consumer holds the last fragments of stage kt: its slot is free
+            if (kt + 2 < nk) stage(kt & 1, ks(kt + 2));
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 15, fgrp = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int chunk = (kk * 4 + fgrp) ^ (lane & 7);
+        a_off[kk] = (wr * RF * 16 + frow) * BK + chunk * 8;
+        b_off[kk] = BMT * BK + (wc * 64 + frow) * BK + chunk * 8;
+    }
+    f32x4 acc[RF][4];
+    init_acc<EPI, RF>(g, acc, n0 + wc * 64, lane);
+    half8 fa[RF], fb[4];
+    auto rd = [&](int buf, int kk) {
+        const half_t* st = lds2 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *(const half8*)(st + b_off[kk] + j * 16 * BK);
+#pragma unroll
+        for (int i = 0; i < RF; ++i) fa[i] = *(const half8*)(st + a_off[kk] + i * 16 * BK);
+    };
+    auto mm = [&]() {
+#pragma unroll
+        for (int i = 0; i < RF; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();                     // stage 0 landed
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        rd(buf, 0);
+        mm();
+        rd(buf, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // this stage's slot is free; stage kt + 1 has landed
+        mm();
+    }
+    __builtin_amdgcn_s_barrier();   // every consumer is done with the stages: reuse them as epilogue slabs
+    epilogue_rows<EPI, RF, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * RF * 16, n0 + wc * 64, lane);
+}
+
 // ---- Persistent form of gemm_k64_kernel: one workgroup per CU walks its XCD's run of tiles, and the two-stage K pipeline
 // simply continues across tile boundaries -- the first two stages of tile t+1 are issued at the last two stage
 // boundaries of tile t and land while tile t's epilogue runs, so a tile no longer starts with an exposed HBM/L2 round trip
@@ -1573,6 +1667,32 @@ static int launch_k64(int epi, const GemmArgs& a, hipStream_t s) {
     return GRIP_OK;
 }
 
+static int launch_k64w(int epi, const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = (a.M + 191) / 192, tiles_n = a.N / 256;
+    constexpr size_t lds = (size_t)2 * (192 + 256) * BK * 2;
+    dim3 grid(tiles_m * tiles_n), block(768);
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_k64w_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_k64w_kernel<E>), grid, block, lds, s, a, tiles_m, tiles_n);                                \
+    } break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_F32)
+        GRIP_GEMM_CASE(EPI_BIAS_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_GELU_F16)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
+        GRIP_GEMM_CASE(EPI_GELUGRAD_F16)
+        default: GRIP_REQUIRE(false, "gemm: the loader-wave 192x256 prototype has no epilogue %d", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
 static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
     constexpr size_t lds = (size_t)2 * 512 * BK * 2 + 8 * 4096;       // two stages + eight 4 KiB slabs = the whole 160 KiB
@@ -1870,6 +1990,14 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     if (variant == 6) {
         GRIP_REQUIRE(can_big && a.N % 256 == 0 && a.K >= 2 * BK, "gemm: 256x256x64 tile needs N %% 256 == 0, K >= 128 and A padded to 256 rows");
         return launch_k64p(epi, a, s);
+    }
+    {
+        static const bool k64w = getenv("GRIP_K64W") && atoi(getenv("GRIP_K64W")) != 0;     // developer A/B
+        if (k64w && variant == 8 && (epi == EPI_BIAS_GELU_F16 || epi == EPI_GELUGRAD_F16)) variant = 9;
+    }
+    if (variant == 9) {      // developer prototype: 192x256 tile with loader waves
+        GRIP_REQUIRE(a.N % 256 == 0 && a.K >= 2 * BK && (int64_t)((a.M + 191) / 192) * 192 <= a.m_pad, "gemm: 192x256x64 loader-wave tile: shape");
+        return launch_k64w(epi, a, s);
     }
     if (variant == 8) {      // (7 is the f32 kernel in the debug hook)
         GRIP_REQUIRE(a.N % 256 == 0 && a.K >= 2 * BK && (int64_t)((a.M + 191) / 192) * 192 <= a.m_pad && epi != EPI_BIAS_RESID_STATS,

@@ -22,7 +22,7 @@ PY
 }
 go() { tag=$1; shift; rm -rf /tmp/vp_$tag; env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/vp_$tag -o r -- python $R/tools/vpt_loop.py > /dev/null 2>&1; summ /tmp/vp_$tag $tag; }
 {
-go prev GRIP_LIB=$R/menghini-neurips23-code_amd/libgrip_prev.so
-go new X=1
+go base X=1
+go k64w GRIP_K64W=1
 } > $R/gpurun_out/exp5.log 2>&1
-grep "total\|ring" $R/gpurun_out/exp5.log | grep -v "', '[0-9]\{4,5\}', '512'" 
+grep "total\|k64" $R/gpurun_out/exp5.log
