@@ -1270,7 +1270,8 @@ __global__ __launch_bounds__(768) void gemm_k64w_kernel(GemmArgs g, int tiles_m,
         mm();
     }
     __builtin_amdgcn_s_barrier();   // every consumer is done with the stages: reuse them as epilogue slabs
-    epilogue_rows<EPI, RF, (EPI == EPI_BIAS_RESID_STATS || EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16 ? 1 : 2)>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * RF * 16, n0 + wc * 64, lane);
+    // (16-row passes: the operand prefetch of 32-row passes does not fit the 170-register budget of three waves per SIMD)
+    epilogue_rows<EPI, RF, 1>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * RF * 16, n0 + wc * 64, lane);
 }
 
 // ---- Persistent form of gemm_k64_kernel: one workgroup per CU walks its XCD's run of tiles, and the two-stage K pipeline
