@@ -43,7 +43,7 @@ def _finish(loss, params, optimizer, logits=None):
     loss.backward()
     gdist.allreduce_mean_([p.grad for p in params if p.grad is not None])
     optimizer.step()
-    optimizer.zero_grad(set_to_none=False)
+    optimizer.zero_grad(set_to_none=True)       # the next backward adopts its gradient tensors (no fill, no add kernels)
     return loss.detach() if logits is None else (loss.detach(), logits.detach())
 
 
