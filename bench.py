@@ -530,7 +530,9 @@ def structured_pool_block(loop):
         dt = time.perf_counter() - t0
         rs = loop.refine_stats
         pred_hist = np.bincount(cls, minlength=a.classes)
-        return {"pool_images": n, "identical_images_per_sec": n / dt, "rows_reencoded_exactly": rs["rows_refined"], "fraction": rs["rows_refined"] / n,
+        return {"pool_images": n, "identical_images_per_sec": n / dt, "rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"],
+                "rows_reencoded_exactly": rs["rows_exact"], "fraction": rs["rows_refined"] / n, "audit_rows": rs["audit_rows"],
+                "audit_max_deviation": rs["audit_max_deviation"], "audit_widened_the_bound": rs["audit_widened"],
                 "rounds": rs["rounds"], "rows_per_round": rs["refined_per_round"], "relative_bound": rs["eps"], "pairs": int(len(img)),
                 "classes_with_a_full_board": int((pred_hist >= a.k).sum()),
                 "note": "same loop, same towers, structured synthetic pool (seeded on the device; not the fixtures' CPU generator)"}
@@ -762,10 +764,12 @@ def main():
                    "comparable_to_earlier_rounds": "rounds 1-2 timed the f16 lists (no index guarantee): compare their `value` with `f16_mode_loop.images_per_sec` "
                                                    "of this line; `value` here is the identical mode (the default of utils.pseudolabel_top_k since round 3)"
                                                    if args.mode == "identical" else "same path as rounds 1-2",
-                   "index_guarantee": ("`value` itself carries it: every timed pass returns the lists of the fp32 (exact-mode) scan -- f16 towers screen the pool, "
-                                       "the error-bounded scan marks the rows whose f16 probabilities cannot decide a comparison the lists depend on, "
-                                       "the f32 towers re-encode those rows, until the scan certifies its lists (pseudolabels.refine_scan; equality with the "
-                                       "exact mode on this very pool is checked in the `exact` block and asserted in tests/test_gpu_identical.py)")
+                   "index_guarantee": ("calibrated bound, audited: every timed pass returns the lists the error-bounded scan CERTIFIES to be the fp32 (exact-mode) "
+                                       "scan's provided every row obeys the measured bound of the tier it was left at -- f16 towers screen the pool, the scan marks "
+                                       "the rows whose probabilities cannot decide a comparison the lists depend on, more accurate towers (split-f16, then f32) "
+                                       "re-encode those, and after certification a hold-out sample of un-refined rows is re-encoded to check the bound "
+                                       "(`identical.audit_*`; pseudolabels.refine_scan).  Equality with the exact mode on this very pool is checked in the "
+                                       "`exact` block of this run and asserted in tests/test_gpu_identical.py")
                                       if args.mode == "identical" else
                                       "none: f16 lists (boundary items may differ from the fp32 scan's); run with --mode identical for the guarantee",
                    "pool_images_per_gpu": args.pool, "pool_images_total": loop.n_total, "classes": args.classes, "prompt_tokens": args.prefix, "k": args.k,
@@ -785,10 +789,18 @@ def main():
         "identical_images_per_sec": (images / loop.t_pl if loop.t_pl else None) if args.mode == "identical" else None,
         "f16_mode_loop": f16_loop,
         "identical": None if rs is None else {
-            "rows_reencoded_exactly": rs["rows_refined"], "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1),
+            "rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"], "rows_reencoded_exactly": rs["rows_exact"], "tiers": rs["tiers"],
+            "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1),
             "calibration_rows": rs["calibration_rows"], "rounds": rs["rounds"], "scans": rs["scans"], "rows_per_round": rs["refined_per_round"],
-            "relative_bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "safety": rs["safety"],
-            "note": "last timed pass; bound = safety x the largest |p_f16 / p_f32 - 1| over every row re-encoded so far"},
+            "relative_bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "relative_bound_split_f16": rs["eps_mid"],
+            "largest_deviation_seen_split_f16": rs["max_deviation_mid"], "safety": rs["safety"],
+            "audit_rows": rs["audit_rows"], "audit_board_rows": rs["audit_board_rows"], "audit_max_deviation": rs["audit_max_deviation"],
+            "audit_widened_the_bound": rs["audit_widened"], "audits": rs["audits"], "audit_rows_split_f16": rs.get("audit_mid_rows", 0),
+            "audit_max_deviation_split_f16": rs.get("audit_max_deviation_mid", 0.0), "unverified_rows": rs["unverified_rows"],
+            "observed_rows": rs["observed_rows"],
+            "note": "last timed pass; bound = safety x the largest relative deviation (by the smaller value) between a tier's probabilities and the better ones that "
+                    "replaced them, over every row re-encoded so far; audit = hold-out rows re-encoded after certification: audit_max_deviation <= relative_bound "
+                    "or the bound is widened and the scan repeats; unverified_rows = rows the lists take on trust within the bound"},
         "train_images_per_sec": train_imgs / loop.t_tr if loop.t_tr else None,
         "algorithmic_tflops": nominal / elapsed / 1e12 / ws,
         "executed_tflops": executed / elapsed / 1e12 / ws,

@@ -37,7 +37,7 @@ typedef enum {
 const char* grip_last_error(void);
 /* ABI version of this header; the host layer refuses a library that reports another one. */
 int grip_abi_version(void);
-#define GRIP_ABI_VERSION 5
+#define GRIP_ABI_VERSION 6
 
 /* ------------------------------------------------------------------------------------------
  * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
@@ -253,12 +253,14 @@ int grip_leaderboard_scan(const float* probs, const int32_t* pred, const int64_t
  * took part in a comparison the intervals could not decide (an undecidable arg-max only counts when one of the candidate classes
  * could admit the image: when all of them certainly reject it the image spills to every class whichever of them is the true
  * arg-max).  *n_ambiguous == 0  =>  the lists written are the lists grip_leaderboard_scan returns on the TRUE probabilities,
- * provided every |p_i[j] / true_i[j] - 1| <= rel_eps[i].  Otherwise the caller re-encodes the marked rows exactly, sets their
+ * provided every |true_i[j] - p_i[j]| <= rel_eps[i] * p_i[j] + abs_eps (abs_eps: absolute slack of the un-refined rows, for softmax outputs in
+ * the denormal range, which have no relative accuracy; rows with rel_eps[i] == 0 are final and carry none).  A row may also carry the bound of an
+ * intermediate tier (0 < rel_eps[i] << the screen's): any mix of per-row bounds is valid.  Otherwise the caller re-encodes the marked rows exactly, sets their
  * rel_eps to 0 and calls again; the marked set grows strictly, so the loop ends (host side: grip_amd.pseudolabels.refine_scan).
  *   k == 10000000 (the reference's "label everything" branch, :27-44): out_img / out_class need capacity n and every row
  *   whose arg-max is undecidable is marked.  Otherwise capacity c * min(k, n) as above.
  *   ambiguous [n] uint8 host (overwritten). */
-int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps,
+int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps, float abs_eps,
                                   int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count,
                                   uint8_t* ambiguous, int64_t* n_ambiguous);
 

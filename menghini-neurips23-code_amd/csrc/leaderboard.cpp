@@ -127,8 +127,11 @@ struct BEntry {
     int64_t rank;
     int32_t img;
 };
-inline BEntry make_entry(float s, float eps, int64_t rank, int32_t img) {
-    return BEntry{(double)s * (1.0 - (double)eps), (double)s * (1.0 + (double)eps), s, eps, rank, img};
+// abs_eps: absolute slack of an un-refined value on top of the relative one -- below ~1e-30 a softmax output has no relative accuracy
+// left (denormals, underflow to 0), so the interval is [s (1 - eps) - abs_eps, s (1 + eps) + abs_eps]; final rows (eps == 0) carry none
+inline BEntry make_entry(float s, float eps, int64_t rank, int32_t img, double abs_eps) {
+    const double a = eps != 0.f ? abs_eps : 0.0;
+    return BEntry{(double)s * (1.0 - (double)eps) - a, (double)s * (1.0 + (double)eps) + a, s, eps, rank, img};
 }
 // outcome of `a.score < x.score` over the true values: 1 certainly true, 0 certainly false, -1 undecidable
 inline int certainly_less(const BEntry& a, const BEntry& x) {
@@ -182,7 +185,7 @@ struct Marks {
 
 struct BoundedScan {
     const float* probs; const int32_t* pred; const int64_t* path_rank; const float* rel_eps;
-    int64_t n; int c; int64_t kk; bool strict;
+    int64_t n; int c; int64_t kk; bool strict; double abs_eps;
     std::vector<BBoard> boards;
     std::vector<double> t_lo;       // per class: T_lo once the board is sorted, -inf before (nothing is dropped then)
     Marks mk;
@@ -267,12 +270,13 @@ struct BoundedScan {
             const float eps = rel_eps[i];
             GRIP_REQUIRE(js >= 0 && js < c, "bounded leaderboard: pred[%lld] = %d out of range", (long long)i, js);
             GRIP_REQUIRE(eps >= 0.f && eps < 1e6f, "bounded leaderboard: rel_eps[%lld] = %g out of range", (long long)i, (double)eps);    // (eps >= 1: the lower bound is <= 0, i.e. "could be anything below")
-            const BEntry x = make_entry(p[js], eps, path_rank[i], (int32_t)i);
+            const BEntry x = make_entry(p[js], eps, path_rank[i], (int32_t)i, abs_eps);
+            const double slack = eps != 0.f ? abs_eps : 0.0;     // hi(p[j]) = p[j] * up + slack
             const double up = 1.0 + (double)eps;
             cand.clear();                                                   // (A)
             if (eps != 0.f)
                 for (int j = 0; j < c; ++j)
-                    if (j != js && (double)p[j] * up >= x.lo) cand.push_back(j);
+                    if (j != js && (double)p[j] * up + slack >= x.lo) cand.push_back(j);
             if (label_all) {
                 if (!cand.empty()) mk.mark(x);
                 continue;
@@ -281,7 +285,7 @@ struct BoundedScan {
             if (!cand.empty()) {
                 bool all_reject = certainly_rejects(js, x);
                 for (size_t q = 0; all_reject && q < cand.size(); ++q)
-                    all_reject = certainly_rejects(cand[q], make_entry(p[cand[q]], eps, x.rank, x.img));
+                    all_reject = certainly_rejects(cand[q], make_entry(p[cand[q]], eps, x.rank, x.img, abs_eps));
                 mk.cat = 1;
                 if (!all_reject) mk.mark(x);
             }
@@ -299,7 +303,7 @@ struct BoundedScan {
                     // is in the final board is certified at the end like any recorded offer).
                     bool spill_irrelevant = true;
                     for (int j = 0; spill_irrelevant && j < c; ++j)
-                        if (j != js) spill_irrelevant = boards[(size_t)j].sorted && (double)p[j] * up < t_lo[(size_t)j];
+                        if (j != js) spill_irrelevant = boards[(size_t)j].sorted && (double)p[j] * up + slack < t_lo[(size_t)j];
                     bool can_defer = eps != 0.f;
                     for (int j = 0; can_defer && !spill_irrelevant && j < c; ++j)
                         if (j != js) can_defer = boards[(size_t)j].sorted;          // an unsorted board loses a rejected offer for good: no deferral
@@ -313,9 +317,9 @@ struct BoundedScan {
                         // image is marked (it is un-refined: eps != 0).
                         spill = false;
                         for (int j = 0; j < c; ++j) {
-                            if (j == js || (double)p[j] * up < t_lo[(size_t)j]) continue;
+                            if (j == js || (double)p[j] * up + slack < t_lo[(size_t)j]) continue;
                             BBoard& b = boards[(size_t)j];
-                            const BEntry y = make_entry(p[j], eps, x.rank, x.img);
+                            const BEntry y = make_entry(p[j], eps, x.rank, x.img, abs_eps);
                             b.cond.push_back(y);
                             b.hi.push(y.hi);
                         }
@@ -336,8 +340,8 @@ struct BoundedScan {
             } else {
                 for (int j = 0; j < c; ++j) {
                     if (j == js) continue;
-                    if ((double)p[j] * up < t_lo[(size_t)j]) continue;      // the common case of (D): certainly irrelevant
-                    offer(j, make_entry(p[j], eps, x.rank, x.img));
+                    if ((double)p[j] * up + slack < t_lo[(size_t)j]) continue;      // the common case of (D): certainly irrelevant
+                    offer(j, make_entry(p[j], eps, x.rank, x.img, abs_eps));
                 }
             }
         }
@@ -387,13 +391,14 @@ struct BoundedScan {
 };
 }  // namespace
 
-extern "C" int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps,
+extern "C" int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps, float abs_eps,
                                              int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count,
                                              uint8_t* ambiguous, int64_t* n_ambiguous) {
     GRIP_REQUIRE(probs && pred && path_rank && rel_eps && out_img && out_class && out_count && ambiguous && n_ambiguous, "bounded leaderboard: null pointer");
     GRIP_REQUIRE(n >= 0 && c > 0 && k > 0, "bounded leaderboard: bad sizes n=%lld c=%d k=%lld", (long long)n, c, (long long)k);
+    GRIP_REQUIRE(abs_eps >= 0.f && abs_eps < 1.f, "bounded leaderboard: abs_eps = %g out of range", (double)abs_eps);
     try {
-        BoundedScan s{probs, pred, path_rank, rel_eps, n, c, std::min<int64_t>(k, std::max<int64_t>(n, 1)), false};
+        BoundedScan s{probs, pred, path_rank, rel_eps, n, c, std::min<int64_t>(k, std::max<int64_t>(n, 1)), false, (double)abs_eps};
         const char* env = getenv("GRIP_SCAN_STRICT");       // developer A/B: certify every comparison of the literal algorithm
         s.strict = env && env[0] == '1';
         int rc = s.run(out_img, out_class, out_count, ambiguous, n_ambiguous, k);

@@ -16,11 +16,66 @@ from . import engine
 K_ALL = 10000000   # utils/clip_pseudolabels.py:27
 
 
-def path_ranks(paths):
-    """Dense rank of every path among all paths under Python's string order (the leaderboard breaks
-    score ties by comparing the path strings, utils/clip_pseudolabels.py:79-82)."""
+def _path_ranks_literal(paths):
     order = {p: i for i, p in enumerate(sorted(set(paths)))}
     return np.fromiter((order[p] for p in paths), dtype=np.int64, count=len(paths))
+
+
+def _path_ranks_bytes(paths):
+    """The same ranks without a Python-level sort: ASCII paths as a fixed-width byte matrix (code-point order == byte order, a shorter
+    string pads with NUL, which sorts first -- as a proper prefix does in Python), common prefix dropped, 8 bytes per big-endian u64
+    column; one SIMD argsort when the first column already separates the strings, a column-wise stable sort otherwise."""
+    n = len(paths)
+    a = np.array(paths, dtype=np.bytes_)        # UnicodeEncodeError for non-ASCII strings: the caller falls back
+    w = a.dtype.itemsize
+    if w == 0:
+        return np.zeros(n, dtype=np.int64)
+    b = a.view(np.uint8).reshape(n, w)
+    if int(b.min()) == 0 and any("\0" in p for p in paths):
+        raise UnicodeEncodeError("ascii", "", 0, 1, "NUL inside a path")      # (padding and content would be confused)
+    varies = b.min(axis=0) != b.max(axis=0)
+    if not varies.any():
+        return np.zeros(n, dtype=np.int64)
+    b = b[:, int(np.argmax(varies)):]
+    w = b.shape[1]
+    c = np.zeros((n, w + (-w) % 8), dtype=np.uint8)
+    c[:, :w] = b
+    cols = c.view(">u8")
+    first = np.ascontiguousarray(cols[:, 0]).astype(np.uint64)
+    order = np.argsort(first)
+    s0 = first[order]
+    if cols.shape[1] > 1 and (s0[1:] == s0[:-1]).any():
+        order = np.lexsort(cols.T[::-1])
+    srt = cols[order]
+    new = np.empty(n, dtype=np.int64)
+    new[0] = 0
+    np.cumsum((srt[1:] != srt[:-1]).any(axis=1), out=new[1:])
+    out = np.empty(n, dtype=np.int64)
+    out[order] = new
+    return out
+
+
+_RANK_CACHE = []        # [(tuple(paths), ranks)], most recent first: GRIP re-labels the same pool every iteration
+
+
+def path_ranks(paths):
+    """Dense rank of every path among all paths under Python's string order (the leaderboard breaks
+    score ties by comparing the path strings, utils/clip_pseudolabels.py:79-82).  Vectorised (0.1 s at 400 000 paths against
+    0.6 s for the literal form, tools/scan_scale.py) and remembered for the last few pools."""
+    key = tuple(paths)
+    for i, (k, r) in enumerate(_RANK_CACHE):
+        if len(k) == len(key) and k == key:          # element-wise; identical string objects compare by pointer
+            if i:
+                _RANK_CACHE.insert(0, _RANK_CACHE.pop(i))
+            return r
+    try:
+        r = _path_ranks_bytes(paths)
+    except (UnicodeEncodeError, TypeError, ValueError):
+        r = _path_ranks_literal(paths)
+    r.setflags(write=False)
+    _RANK_CACHE.insert(0, (key, r))
+    del _RANK_CACHE[4:]
+    return r
 
 
 @torch.no_grad()
@@ -45,70 +100,190 @@ def leaderboard(probs, pred, paths, class_labels, k):
 
 
 # ------------------------------------------------------------------------------------------ screen and refine
-REFINE_CALIB_ROWS = 256     # rows re-encoded exactly up front to measure the f16 towers' deviation on THIS pool
+REFINE_CALIB_ROWS = 256     # rows re-encoded exactly up front to measure the cheaper tiers' deviation on THIS pool
 REFINE_SAFETY = 2.0         # bound = safety x the largest deviation seen on any row re-encoded so far (it only ever grows)
+REFINE_ESCALATE_AFTER = 8   # rounds after which whatever is still un-refined moves up a tier in one go (pathological pools only, see refine_scan)
+REFINE_AUDIT_ROWS = 256     # un-refined rows re-encoded AFTER the scan certified its lists, to check the bound they were trusted to ($GRIP_REFINE_AUDIT)
+REFINE_MAX_AUDITS = 4       # audits that may each widen the bound before everything left is simply re-encoded
+REFINE_ABS_EPS = 1e-30      # absolute slack of an un-refined probability: below this a softmax output has no relative accuracy (denormals, 0)
+_EPS_CAP = 9e5              # grip_leaderboard_scan_bounded takes bounds below 1e6 (a bound >= 1 already means "anything below")
 
 
-REFINE_ESCALATE_AFTER = 8   # rounds after which whatever is still un-refined is re-encoded in one go (pathological pools only, see refine_scan)
+def audit_rows_default():
+    import os
+    v = os.environ.get("GRIP_REFINE_AUDIT", "")
+    return int(v) if v.strip() else REFINE_AUDIT_ROWS
 
 
-def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safety=REFINE_SAFETY, max_rounds=64):
+def _deviation(approx, better, abs_eps):
+    """Largest relative deviation between the approximate probabilities `approx` and the more accurate `better` of the same
+    rows, beyond the absolute slack, relative to the SMALLER of the two values (so it bounds |better - approx| / approx, the form
+    the scan's intervals use, and |approx / better - 1|, the form include/grip_amd.h states, alike).  Pairs that both lie inside
+    the absolute slack are covered by it; a pair with one value at 0 and the other above the slack deviates infinitely."""
+    a, b = np.asarray(approx, dtype=np.float64), np.asarray(better, dtype=np.float64)
+    big = np.maximum(a, b) > abs_eps
+    if not big.any():
+        return 0.0
+    d = np.maximum(np.abs(a - b)[big] - abs_eps, 0.0)
+    m = np.minimum(a, b)[big]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.where(d > 0, d / m, 0.0)
+    return float(np.max(r))
+
+
+def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safety=REFINE_SAFETY, max_rounds=64, mid_rows=None,
+                audit=None, abs_eps=REFINE_ABS_EPS):
     """Leaderboard lists of the reference's fp32 scan from probabilities of the f16 towers (utils/clip_pseudolabels.py:38-112).
 
-    `probs` [N, C] f32 / `pred` [N] come from the f16 image tower (modified in place); `exact_rows(idx)` returns the exact
-    (f32-tower) probabilities and arg-max of the rows `idx` (ascending int64 array).  The f16 rows are trusted only up to a relative
-    bound eps = safety x (largest |p16 / p32 - 1| over every row re-encoded so far, starting with `calib` rows -- at most 1/16 of
-    the pool, at least 16 -- spread evenly over it); grip_leaderboard_scan_bounded marks every un-refined row that takes part in a comparison the bound
-    cannot decide; those rows are re-encoded exactly and the scan repeats until nothing is marked and the bound has not moved.
-    The final scan takes, decision by decision, the decisions of the scan over the all-f32 probabilities, so the lists are the
-    exact mode's lists (asserted at N = 50 000 in tests/test_gpu_identical.py) at a fraction of its cost.
+    `probs` [N, C] f32 / `pred` [N] come from the f16 image tower (the SCREEN; modified in place); `exact_rows(idx)` returns the
+    exact (f32-tower) probabilities and arg-max of the rows `idx` (ascending int64 array); `mid_rows(idx)`, optional, the same from
+    a MIDDLE tier (the split-f16 tower: far more accurate than the screen, several times cheaper than the f32 tower).  A row
+    sits at level 0 (screen), 1 (middle) or 2 (exact, final).  Level-0 / level-1 values are trusted only up to a relative bound
+    eps[level] = safety x (largest deviation seen so far between a value of that level and the better value that later replaced it),
+    plus an absolute slack `abs_eps` for values in the denormal range; the bounds start from `calib` rows -- at most 1/16 of the pool,
+    at least 16 -- spread evenly over it, which go through every tier.  grip_leaderboard_scan_bounded marks every non-final row
+    that takes part in a comparison its bound cannot decide; marked rows move up one tier and the scan repeats until nothing is
+    marked and no bound has moved: the lists are then certified, decision by decision, to be those of the scan over the all-f32
+    probabilities PROVIDED every non-final row obeys its bound.
+
+    That proviso is a measured bound, not a theorem about f16 arithmetic, so it is AUDITED: after certification `audit` (default
+    256, $GRIP_REFINE_AUDIT; 0 = off; at most 1/16 of the pool) rows still at level 0 -- half of them members of the final boards where there are any, the rest
+    drawn uniformly from the pool (seeded: every rank draws the same rows) -- are re-encoded by the next tier; if one of them turns
+    out to deviate by MORE than the bound it was trusted to, the bound was understated: it is widened to safety x that deviation, the scan
+    repeats under it and is audited again (at most REFINE_MAX_AUDITS times, after which every row left is re-encoded).  stats reports the audit (`audit_rows`, `audit_max_deviation`, `audit_widened`), the rows the final lists
+    still take on trust (`unverified_rows`) and the number of rows every bound rests on (`observed_rows`).
     Returns (img, cls, stats)."""
     n, c = probs.shape
-    refined = np.zeros(n, dtype=bool)
-    dev_max = 0.0
-    floor = np.float32(1e-30)       # below this a probability has no relative accuracy left to speak of (denormal range)
+    audit = audit_rows_default() if audit is None else int(audit)
+    if audit > 0:
+        audit = min(n, max(16, min(audit, n // 16)))       # like the calibration sample: at most 1/16 of the pool, at least 16 rows
+    level = np.zeros(n, dtype=np.int8)
+    dev = [0.0, 0.0]                # largest deviation seen of a level-0 / level-1 value from the better value that replaced it
+    n_mid = n_exact = 0
 
-    def refine(idx):
-        nonlocal dev_max
+    def to_exact(idx):
+        nonlocal n_exact
         idx = np.asarray(idx, dtype=np.int64)
         if idx.size == 0:
             return
         p32, a32 = exact_rows(idx)
-        p16 = probs[idx]
-        ok = (p16 > floor) & (p32 > floor)
-        if ok.any():
-            dev_max = max(dev_max, float(np.max(np.abs(p16[ok].astype(np.float64) - p32[ok]) / p16[ok])))
+        for lv in (0, 1):
+            sel = level[idx] == lv
+            if sel.any():
+                dev[lv] = max(dev[lv], _deviation(probs[idx[sel]], p32[sel], abs_eps))
         probs[idx] = p32
         pred[idx] = a32
-        refined[idx] = True
+        level[idx] = 2
+        n_exact += idx.size
 
-    stats = {"rows": n, "calibration_rows": 0, "rounds": 0, "scans": 0}
+    def to_mid(idx):
+        nonlocal n_mid
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size == 0:
+            return
+        pm, am = mid_rows(idx)
+        # the middle tier's value is itself only known to eps[1]: a screen value within d of it is within d (1 + eps1) + eps1 of the truth
+        d = _deviation(probs[idx], pm, abs_eps)
+        dev[0] = max(dev[0], d * (1.0 + eps[1]) + eps[1])
+        probs[idx] = pm
+        pred[idx] = am
+        level[idx] = 1
+        n_mid += idx.size
+
+    def up(idx):
+        """Move rows up one tier: level 0 -> middle tier where there is one, everything else -> exact."""
+        idx = np.asarray(idx, dtype=np.int64)
+        lo = idx[level[idx] == 0] if mid_rows is not None else idx[:0]
+        hi = idx[level[idx] == 1] if mid_rows is not None else idx
+        to_mid(lo)
+        to_exact(hi)
+
+    def bound(lv):
+        return min(safety * dev[lv], _EPS_CAP)
+
+    stats = {"rows": n, "calibration_rows": 0, "rounds": 0, "scans": 0, "audits": 0, "audit_rows": 0, "audit_board_rows": 0, "audit_max_deviation": 0.0,
+             "audit_widened": False}
+    eps = [0.0, 0.0]
     if n == 0:
-        return np.empty(0, np.int32), np.empty(0, np.int32), dict(stats, rows_refined=0, eps=0.0, max_deviation=0.0)
+        return np.empty(0, np.int32), np.empty(0, np.int32), dict(stats, rows_refined=0, rows_mid=0, rows_exact=0, eps=0.0, eps_mid=0.0, max_deviation=0.0,
+                                                                    max_deviation_mid=0.0, refined_per_round=[], safety=float(safety), unverified_rows=0,
+                                                                    observed_rows=0, tiers=2 + (mid_rows is not None))
     # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than 16 (a bound from one or two rows is no bound)
-    refine(np.unique(np.linspace(0, n - 1, min(n, max(16, min(calib, n // 16)))).astype(np.int64)))
-    stats["calibration_rows"] = int(refined.sum())
-    eps = safety * dev_max
+    cal = np.unique(np.linspace(0, n - 1, min(n, max(16, min(calib, n // 16)))).astype(np.int64))
+    if mid_rows is not None:
+        pm_cal, _ = mid_rows(cal)
+        n_mid += cal.size
+    to_exact(cal)
+    if mid_rows is not None:
+        dev[1] = _deviation(pm_cal, probs[cal], abs_eps)
+    stats["calibration_rows"] = int(cal.size)
+    eps = [bound(0), bound(1)]
     per_round = []
+    g = np.random.default_rng(1000003 * n + int(min(k, 1 << 30)))      # the audit's draw: a function of the problem only (identical on every rank)
     while True:
-        rel = np.where(refined, np.float32(0), np.float32(eps)).astype(np.float32)
-        img, cls, amb = engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k)
+        rel = np.where(level == 2, np.float32(0), np.where(level == 1, np.float32(eps[1]), np.float32(eps[0]))).astype(np.float32)
+        img, cls, amb = engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps)
         stats["scans"] += 1
-        todo = np.flatnonzero(amb & ~refined)
-        if todo.size == 0 and safety * dev_max <= eps:
-            break
+        todo = np.flatnonzero(amb & (level < 2))
+        moved = bound(0) > eps[0] or bound(1) > eps[1]
+        if todo.size == 0 and not moved:
+            # certified under the current bounds: audit rows that are still taken on trust
+            pending = np.flatnonzero(level == 0)
+            if audit <= 0 or pending.size == 0:
+                break
+            if stats["audits"] >= REFINE_MAX_AUDITS:      # every audit so far widened the bound: it cannot be trusted on this pool
+                stats["escalated"] = True
+                up(pending)
+                per_round.append(int(pending.size))
+                stats["rounds"] += 1
+                eps = [max(eps[0], bound(0)), max(eps[1], bound(1))]
+                continue
+            in_board = np.zeros(n, dtype=bool)
+            if k != K_ALL:
+                in_board[np.asarray(img, dtype=np.int64)] = True
+            members = pending[in_board[pending]]
+            n_b = min(members.size, audit // 2)
+            pick_b = g.choice(members, size=n_b, replace=False) if n_b else np.empty(0, np.int64)
+            others = pending[~in_board[pending]] if n_b else pending
+            n_o = min(others.size, audit - n_b)
+            pick_o = g.choice(others, size=n_o, replace=False) if n_o else np.empty(0, np.int64)
+            sample = np.unique(np.concatenate([pick_b, pick_o]).astype(np.int64))
+            before = list(dev)
+            dev[0] = dev[1] = 0.0
+            up(sample)
+            if mid_rows is not None:                        # ... and a few rows the middle tier is trusted on go through the exact tower
+                mids = np.flatnonzero(level == 1)
+                sample_mid = np.sort(g.choice(mids, size=min(mids.size, max(audit // 8, 1)), replace=False)) if mids.size else mids
+                to_exact(sample_mid)
+                stats["audit_mid_rows"] = stats.get("audit_mid_rows", 0) + int(sample_mid.size)
+                stats["audit_max_deviation_mid"] = max(stats.get("audit_max_deviation_mid", 0.0), float(dev[1]))
+            seen = list(dev)
+            stats["audits"] += 1
+            stats["audit_rows"] += int(sample.size)
+            stats["audit_board_rows"] += int(n_b)
+            stats["audit_max_deviation"] = max(stats["audit_max_deviation"], float(seen[0]))
+            if seen[0] <= eps[0] and seen[1] <= eps[1]:
+                dev[0], dev[1] = before                     # a hold-out check of the bounds, passed: they stay what the lists were certified under
+                break
+            # a row beyond the bound it was trusted to: the bound was understated -- widen it (safety x what was just seen) and scan again
+            dev[0], dev[1] = max(before[0], seen[0]), max(before[1], seen[1])
+            stats["audit_widened"] = True
+            eps = [max(eps[0], bound(0)), max(eps[1], bound(1))]
+            continue
         if stats["rounds"] >= max_rounds:
-            raise RuntimeError(f"refine_scan: no fixed point after {max_rounds} rounds ({int(refined.sum())} of {n} rows refined)")
+            raise RuntimeError(f"refine_scan: no fixed point after {max_rounds} rounds ({int((level > 0).sum())} of {n} rows refined)")
         if stats["rounds"] >= REFINE_ESCALATE_AFTER:
             # Heavily tied scores can keep a board in the reference's unsorted regime, where every comparison has to be certain and a
-            # round only advances a few images in dataset order: stop trickling and take the exact tower to everything that is left.
-            todo = np.flatnonzero(~refined)
+            # round only advances a few images in dataset order: stop trickling and move everything that is left up a tier.
+            todo = np.flatnonzero(level < 2)
             stats["escalated"] = True
-        refine(todo)
+        up(todo)
         per_round.append(int(todo.size))
         stats["rounds"] += 1
-        eps = max(eps, safety * dev_max)
-    stats.update(rows_refined=int(refined.sum()), refined_per_round=per_round, eps=float(eps), max_deviation=float(dev_max), safety=float(safety))
+        eps = [max(eps[0], bound(0)), max(eps[1], bound(1))]
+    stats.update(rows_refined=int((level > 0).sum()), rows_mid=int(n_mid), rows_exact=int(n_exact), refined_per_round=per_round, eps=float(eps[0]),
+                 eps_mid=float(eps[1]), max_deviation=float(dev[0]), max_deviation_mid=float(dev[1]), safety=float(safety),
+                 unverified_rows=int((level == 0).sum()), observed_rows=int((level > 0).sum()), tiers=2 + (mid_rows is not None), abs_eps=float(abs_eps))
     return img, cls, stats
 
 
@@ -135,17 +310,20 @@ def take_images(images, idx):
 
 @torch.no_grad()
 def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_labels, k, chunk=880, exact_chunk=880, prefix=None,
-                    argmax_on="probs", streams=2, emb16=None):
+                    argmax_on="probs", streams=2, emb16=None, visual_mid=None, mid_chunk=880):
     """(filepaths, labels) of the reference's fp32 pseudolabel scan (utils/clip_pseudolabels.py:24-112) at close to the f16
     towers' throughput: the whole pool goes through the f16 vision tower `visual16` (sharded over ranks, one all-gather), the
-    head scores it against the EXACT text features `txt_exact`, and refine_scan re-encodes with the f32 tower `visual32` only the
-    rows whose f16 probabilities cannot decide a comparison the lists depend on (each rank re-encodes the marked rows of its own
-    shard; one small all-gather per round).  Bit-for-bit the lists of the exact mode (tests/test_gpu_identical.py)."""
+    head scores it against the EXACT text features `txt_exact`, and refine_scan re-encodes only the rows whose probabilities cannot
+    decide a comparison the lists depend on -- with the split-f16 tower `visual_mid` (precision 2) where there is one, and with the
+    f32 tower `visual32` what that tier cannot decide either (each rank re-encodes the marked rows of its own shard; one small
+    all-gather per round and tier).  The lists are the exact mode's lists provided every row obeys the measured bound of the tier it
+    was left at; the bound is calibrated on this pool, audited on a hold-out sample after certification and reported in
+    LAST_REFINE_STATS (asserted equal to the exact mode at N = 50 000 in tests/test_gpu_identical.py)."""
     global LAST_REFINE_STATS
     n = len(paths)
     if n == 0:
-        LAST_REFINE_STATS = {"rows": 0, "rows_refined": 0, "rounds": 0, "scans": 0, "calibration_rows": 0, "refined_per_round": [], "eps": 0.0, "max_deviation": 0.0,
-                             "safety": REFINE_SAFETY, "rows_refined_this_rank": 0}
+        _, _, LAST_REFINE_STATS = refine_scan(np.empty((0, max(len(class_labels), 1)), np.float32), np.empty(0, np.int32), np.empty(0, np.int64), k, None)
+        LAST_REFINE_STATS["rows_refined_this_rank"] = 0
         return [], []
     emb = emb16 if emb16 is not None else encode_pool(visual16, images, chunk=chunk, prefix=prefix)
     dev = emb.device
@@ -153,20 +331,24 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
     probs_h = probs.cpu().numpy()
     pred_h = (am_p if argmax_on == "probs" else am_l).cpu().numpy()
     lo, hi, _ = gdist.shard_range(n)
-    encoded = [0]
+    encoded = {"exact": 0, "mid": 0}
 
-    def exact_rows(idx):
-        mine = idx[(idx >= lo) & (idx < hi)]
-        local = torch.empty(len(mine), visual32.embed_dim, dtype=torch.float32, device=dev)
-        if len(mine):
-            visual32.encode_chunks(lambda a, b: take_images(images, mine[a:b]), local, 0, len(mine), exact_chunk, prefix, streams=1)
-        encoded[0] += len(mine)
-        rows = gdist.allgather_selected(local, idx, n)
-        _, p, al, ap = engine.cosine_head(rows, txt_exact, scale)
-        return p.cpu().numpy(), (ap if argmax_on == "probs" else al).cpu().numpy()
+    def rows_through(tower, tier, tier_chunk):
+        def rows(idx):
+            mine = idx[(idx >= lo) & (idx < hi)]
+            local = torch.empty(len(mine), tower.embed_dim, dtype=torch.float32, device=dev)
+            if len(mine):
+                tower.encode_chunks(lambda a, b: take_images(images, mine[a:b]), local, 0, len(mine), tier_chunk, prefix, streams=1)
+            encoded[tier] += len(mine)
+            got = gdist.allgather_selected(local, idx, n)
+            _, p, al, ap = engine.cosine_head(got, txt_exact, scale)
+            return p.cpu().numpy(), (ap if argmax_on == "probs" else al).cpu().numpy()
+        return rows
 
-    img, cls, stats = refine_scan(probs_h, pred_h, path_ranks(paths), k, exact_rows)
-    stats["rows_refined_this_rank"] = encoded[0]
+    img, cls, stats = refine_scan(probs_h, pred_h, path_ranks(paths), k, rows_through(visual32, "exact", exact_chunk),
+                                  mid_rows=rows_through(visual_mid, "mid", mid_chunk) if visual_mid is not None else None)
+    stats["rows_refined_this_rank"] = encoded["exact"] + encoded["mid"]
+    stats["rows_exact_this_rank"], stats["rows_mid_this_rank"] = encoded["exact"], encoded["mid"]
     LAST_REFINE_STATS = stats
     return [paths[i] for i in img], [class_labels[int(c)] for c in cls]
 

@@ -1,0 +1,241 @@
+"""ORACLE (test infrastructure) -- G9: fixtures for `assign_pseudo_labels`.  Runs ONLY in the build
+container (imports the reference from /root/reference, unmodified):
+
+    python oracle/gen_golden_assign.py            # ~2 min on 8 cores; writes tests/golden/assign_{small,vitb16}.npz
+
+The reference's own `assign_pseudo_labels` of three strategy files -- one per prompt modality and learning paradigm --
+
+    methods/transductive_zsl/multimodal_fpl.py:194-285        MultimodalFPL  (UPT: both towers + the mixer PER IMAGE, :223)
+    methods/semi_supervised_learning/textual_fpl.py:195-283   TextualFPL     (trained text prompt once :203-205, frozen image tower per image)
+    methods/unsupervised_learning/visual_fpl.py:185-328       VisualFPL      (hand-written text prompts once :187-198, prompted ViT per image)
+
+is executed as it stands (the file is imported with its missing base class stubbed, exactly as oracle/gen_golden.py reaches the
+FPL losses) with `self` = a namespace holding what the method reads: `model` = the REFERENCE's own UPTModel / TextPrefixModel /
+ImagePrefixModel (models/prompts_models.py, unmodified) over the CPU fp32 oracle CLIP with prompts moved away from their init,
+`clip_model`, `transform`, `label_to_idx`, `classes` / `unseen_classes`, `template`, `device`.  Images are the seeded
+class-structured pool of grip_amd.methods.main.synthetic_pool (regenerated from the seed on the GPU box); `Image.open` is
+replaced by a lookup into it (the PIL decode is SURVEY 8f-2, pinned elsewhere).
+
+Stored per case: the (filepaths, labels) the reference method returned, the fp32 probabilities it compared (rebuilt from the
+features its model calls returned, with the method's own tensor expressions on the same [1, E] x [E, C] shapes), the features, the
+decision margin of the scan (oracle.leaderboard.scan_margin), and the prompt tensors.  Before writing, the oracle's literal
+leaderboard (oracle/leaderboard.py) over those probabilities must reproduce the reference's lists, and the oracle restatements of
+the wrappers (oracle/wrappers.py) must reproduce its features."""
+import importlib.util
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)        # `import clip` -> oracle/clip
+sys.path.insert(0, REF)         # `import models`, `import utils` -> the reference
+
+import clip  # noqa: E402  (oracle stand-in)
+import grip_amd  # noqa: E402,F401
+from grip_amd import config as gcfg, rng, weights  # noqa: E402
+from grip_amd.methods.main import synthetic_pool  # noqa: E402  (seeded data recipe only -- no engine code)
+import models as RM  # noqa: E402  (REFERENCE, unmodified)
+from oracle import leaderboard as LB, wrappers as W  # noqa: E402
+
+SEED = 900          # default rng seed of the prompt tensors / mixer weights (a case may carry its own)
+TEMPLATE = "a photo of a {}"
+
+
+def load_strategy_file(rel, pkg, base_name):
+    """Import one reference strategy file with its (missing upstream) base class stubbed."""
+    stub = types.ModuleType(pkg)
+    setattr(stub, base_name, type(base_name, (), {}))
+    stub.__path__ = []
+    sys.modules.setdefault("methods", types.ModuleType("methods"))
+    sys.modules[pkg] = stub
+    spec = importlib.util.spec_from_file_location("_ref_" + rel.replace("/", "_"), os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _FakeImg:
+    def __init__(self, idx):
+        self.idx = idx
+
+    def convert(self, mode):
+        return self
+
+
+class _Dataset:
+    def __init__(self, paths):
+        self.filepaths = list(paths)
+        self.labels = None
+        self.label_id = False
+
+
+class _Rec:
+    """Transparent recorder around a callable attribute of `self`: returns what the wrapped call returns, keeps a copy."""
+
+    def __init__(self, f):
+        self.__dict__["_f"] = f
+        self.__dict__["calls"] = []
+
+    def __call__(self, *a, **k):
+        out = self._f(*a, **k)
+        self.calls.append(out)
+        return out
+
+    def __getattr__(self, name):
+        return getattr(self._f, name)
+
+    def __setattr__(self, name, value):          # `self.model.classes = ...` (textual_fpl.py:202) lands on the real model
+        setattr(self._f, name, value)
+
+
+def prompt(seed, tag, name, shape):
+    """A prompt tensor away from its N(0, 0.02) init (as after some training): init + N(0, 0.05)."""
+    a = rng.normal(seed, rng.stream_id(f"{tag}.{name}.init"), shape, 0.0, 0.02)
+    b = rng.normal(seed, rng.stream_id(f"{tag}.{name}.move"), shape, 0.0, 0.05)
+    return torch.from_numpy((a + b).astype(np.float32))
+
+
+CASES = {
+    # (modality, strategy file, package, stubbed base, class, n_classes, n_per_class, pool seed, k, P, prompt seed)
+    "small": [
+        ("multi", "methods/transductive_zsl/multimodal_fpl.py", "methods.transductive_zsl", "MultimodalPrompt", "MultimodalFPL", 6, 40, 23, 8, 4, 902),
+        ("text", "methods/semi_supervised_learning/textual_fpl.py", "methods.semi_supervised_learning", "TextualPrompt", "TextualFPL", 6, 40, 29, 16, 4, 904),
+        ("image", "methods/unsupervised_learning/visual_fpl.py", "methods.unsupervised_learning", "VisualPrompt", "VisualFPL", 6, 40, 31, 5, 4, 902),
+    ],
+    "vitb16": [
+        ("multi", "methods/transductive_zsl/multimodal_fpl.py", "methods.transductive_zsl", "MultimodalPrompt", "MultimodalFPL", 5, 14, 41, 6, 4, SEED),
+        ("text", "methods/semi_supervised_learning/textual_fpl.py", "methods.semi_supervised_learning", "TextualPrompt", "TextualFPL", 5, 14, 43, 4, 16, SEED),
+        ("image", "methods/unsupervised_learning/visual_fpl.py", "methods.unsupervised_learning", "VisualPrompt", "VisualFPL", 5, 14, 47, 3, 16, SEED),
+    ],
+}
+ENCODER = {"small": "small", "vitb16": "ViT-B/16"}
+
+
+def label_ids(classes):
+    """Global label ids that are neither contiguous nor in class order (the boards are keyed by them, :208-211)."""
+    return {c: 3 * ((5 * i + 2) % len(classes)) + 1 for i, c in enumerate(classes)}
+
+
+def run_case(group, case, out):
+    modality, rel, pkg, base, cls_name, n_classes, n_per_class, pool_seed, k, P, pseed = case
+    name = ENCODER[group]
+    tag = f"{modality}"
+    om, _ = clip.load(name)
+    d = gcfg.get_dims(name)
+    classes, files, images, _ = synthetic_pool(n_classes, n_per_class, d.image_resolution, pool_seed)
+    paths = [f"/data/synthetic/train/{f}" for f in files]
+    index = {p: i for i, p in enumerate(paths)}
+    l2i = label_ids(classes)
+    unseen = classes[2:] if modality == "multi" else classes          # trzsl: boards over the unseen classes only (:196-199)
+    mod = load_strategy_file(rel, pkg, base)
+    mod.Image = types.SimpleNamespace(open=lambda path: _FakeImg(index[path]))
+    me = types.SimpleNamespace(label_to_idx=l2i, classes=classes, seen_classes=classes[:2] if modality == "multi" else classes,
+                               unseen_classes=unseen, device="cpu", template=TEMPLATE, transform=lambda img: images[img.idx],
+                               config=types.SimpleNamespace(N_PSEUDOSHOTS=k))
+    clip_rec = types.SimpleNamespace(logit_scale=om.logit_scale, encode_image=_Rec(om.encode_image), encode_text=_Rec(om.encode_text))
+    me.clip_model = clip_rec
+    ref_img = RM.CustomImageEncoder(om.visual)
+    ref_txt = RM.CustomTextEncoder(om, "cpu", torch.float32)
+    if modality == "multi":
+        coop, vpt = prompt(pseed, f"{group}.{tag}", "coop", (1, P, d.transformer_width)), prompt(pseed, f"{group}.{tag}", "vpt", (1, P, d.vision_width))
+        mixer = {kk: torch.from_numpy(v) for kk, v in weights.init_upt_mixer(d.transformer_width, d.vision_width, 128, pseed).items()}
+        model = RM.UPTModel(coop.clone(), vpt.clone(), None, ref_img, ref_txt, unseen, 128, device="cpu", dtype=torch.float32)
+        missing, unexpected = model.load_state_dict(mixer, strict=False)
+        assert not unexpected, unexpected
+        out[f"{tag}.coop"], out[f"{tag}.vpt"] = coop.numpy(), vpt.numpy()
+    elif modality == "text":
+        prefix = prompt(pseed, f"{group}.{tag}", "prefix", (1, P, d.transformer_width))
+        model = RM.TextPrefixModel(prefix.clone(), ref_txt, unseen, device="cpu")
+        out[f"{tag}.prefix"] = prefix.numpy()
+    else:
+        prefix = prompt(pseed, f"{group}.{tag}", "prefix", (P, d.vision_width))
+        model = RM.ImagePrefixModel(prefix.clone(), ref_img, device="cpu")
+        out[f"{tag}.prefix"] = prefix.numpy()
+    model.eval()
+    me.model = _Rec(model)
+    ds = _Dataset(paths)
+    t0 = time.time()
+    with torch.no_grad():
+        res = getattr(mod, cls_name).assign_pseudo_labels(me, k, ds)
+    assert res is ds and ds.label_id is True
+    fp, lab = list(ds.filepaths), [int(x) for x in ds.labels]
+
+    # the probabilities the method compared, from the features its calls returned (same expressions, same shapes)
+    scale = om.logit_scale.exp()
+    n = len(paths)
+    if modality == "multi":
+        assert len(me.model.calls) == n
+        img_f = [c[1] for c in me.model.calls]
+        txt_f = [c[0] for c in me.model.calls]                         # the text tower ran once per image (:223)
+        assert all(torch.equal(t, txt_f[0]) for t in txt_f)            # ... on identical inputs: a pure function
+    elif modality == "text":
+        assert len(me.model.calls) == 1 and len(clip_rec.encode_image.calls) == n
+        img_f, txt_f = clip_rec.encode_image.calls, [me.model.calls[0]] * n
+    else:
+        assert len(me.model.calls) == n and len(clip_rec.encode_text.calls) == 1
+        img_f, txt_f = me.model.calls, [clip_rec.encode_text.calls[0]] * n
+    logits = []
+    for i in range(n):
+        t = txt_f[i] / txt_f[i].norm(dim=-1, keepdim=True)
+        f = img_f[i] / img_f[i].norm(dim=-1, keepdim=True)
+        logits.append((scale * f @ t.t())[0])
+    logits = torch.stack(logits)
+    probs = logits.softmax(dim=-1).numpy().astype(np.float32)
+    pred = torch.argmax(logits, dim=1).numpy()                          # :222: arg-max on the LOGITS
+    ids = [l2i[c] for c in unseen]
+    got = LB.leaderboard_scan(probs, pred, paths, ids, k)
+    assert (list(got[0]), list(got[1])) == (fp, lab), f"{group}.{tag}: oracle scan over the recorded probabilities != reference lists"
+    # oracle restatements of the wrappers reproduce the features the reference's models returned
+    x = images
+    with torch.no_grad():
+        if modality == "multi":
+            ce, ve = W.upt_mixer(mixer, coop, vpt)
+            o_txt = W.text_forward(om, clip.tokenize(W.coop_prompt_strings(P, unseen)), ce)
+            o_img = W.vision_forward(om.visual, x, ve)
+        elif modality == "text":
+            o_txt = W.text_forward(om, clip.tokenize(W.coop_prompt_strings(P, unseen)), prefix)
+            o_img = W.vision_forward(om.visual, x, None)
+        else:
+            o_txt = W.text_forward(om, clip.tokenize(W.format_prompt_strings(TEMPLATE, unseen)), None)
+            o_img = W.vision_forward(om.visual, x, prefix)
+    ref_img_f = torch.cat(img_f)
+    err_i = ((o_img - ref_img_f).norm(dim=1) / ref_img_f.norm(dim=1)).max().item()
+    err_t = ((o_txt - txt_f[0]).norm(dim=1) / txt_f[0].norm(dim=1)).max().item()
+    assert err_i <= 2e-5 and err_t <= 2e-5, (err_i, err_t)               # batched vs batch-1 fp32: summation order only
+    margin = LB.scan_margin(probs, pred, k)
+    sizes = {j: lab.count(j) for j in ids}
+    print(f"{group}.{tag}: {n} images, {len(unseen)} classes, k={k}: {len(fp)} pairs {sizes}, arg-max histogram {np.bincount(pred, minlength=len(unseen)).tolist()}, "
+          f"margin {margin:.2e}, wrapper restatement err {err_i:.1e}/{err_t:.1e}, {time.time() - t0:.0f} s", flush=True)
+    out[f"{tag}.meta"] = json.dumps({"encoder": name, "modality": modality, "reference": f"{rel}::{cls_name}.assign_pseudo_labels", "n_classes": n_classes,
+                                     "n_per_class": n_per_class, "pool_seed": pool_seed, "k": k, "P": P, "prompt_seed": pseed, "classes": classes,
+                                     "unseen": unseen, "label_to_idx": l2i, "paths": paths, "lists": [fp, lab]})
+    out[f"{tag}.probs"] = probs
+    out[f"{tag}.pred"] = pred.astype(np.int32)
+    out[f"{tag}.img_feats"] = ref_img_f.numpy()
+    out[f"{tag}.txt_feats"] = txt_f[0].numpy()
+    out[f"{tag}.margin"] = np.float64(margin)
+
+
+def main():
+    """python oracle/gen_golden_assign.py [small] [vitb16]   (no argument = both)"""
+    torch.manual_seed(0)
+    groups = sys.argv[1:] or ["small", "vitb16"]
+    for group in groups:
+        out = {}
+        for case in CASES[group]:
+            run_case(group, case, out)
+        path = os.path.join(REPO, "tests", "golden", f"assign_{group}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    main()

@@ -188,3 +188,112 @@ def test_tied_scores_escalate_instead_of_trickling():
     want = cbind.leaderboard_ref(p32, a32, paths, list(range(8)), 1)
     got, st = _refine(p32, a32, p16, a16, paths, 1, calib=8)
     assert got == want and st.get("escalated") and st["rounds"] <= 10
+
+
+# ------------------------------------------------------------------------------------------ three tiers, audit, absolute slack (r04)
+def _refine3(p32, a32, pmid, p16, a16, paths, k, **kw):
+    """refine_scan with a middle tier: rows may go screen -> middle -> exact; no tier is asked for a row twice."""
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    asked = {"mid": [], "exact": []}
+
+    def exact_rows(idx):
+        asked["exact"].append(idx.copy())
+        return p32[idx], a32[idx]
+
+    def mid_rows(idx):
+        asked["mid"].append(idx.copy())
+        return pmid[idx], pmid[idx].argmax(1).astype(np.int32)
+
+    img, cls, st = pl.refine_scan(p16.copy(), a16.copy(), pl.path_ranks(paths), k, exact_rows, mid_rows=mid_rows, **kw)
+    for name in asked:
+        every = np.concatenate(asked[name]) if asked[name] else np.empty(0, np.int64)
+        assert len(np.unique(every)) == len(every) == st["rows_" + name]
+    return ([paths[i] for i in img], [int(j) for j in cls]), st
+
+
+@pytest.mark.parametrize("n,c,k,spread,sigma,quantise,dup,dominant", CASES[2:])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_three_tiers_end_in_the_exact_lists_with_few_exact_rows(n, c, k, spread, sigma, quantise, dup, dominant, seed):
+    """Middle tier 100x more accurate than the screen (what the split-f16 tower is to the f16 one): same lists as the exact scan; the exact
+    tower sees the calibration rows, the audit's handful and the few rows the middle tier's bound cannot decide."""
+    from oracle import cbind
+    p32, a32, p16, a16, paths = _pool(n, c, spread, sigma, seed * 77 + n, quantise, dup, dominant)
+    r = np.random.RandomState(seed + 5)
+    pmid = (p32.astype(np.float64) * (1.0 + np.clip(r.randn(n, c), -4, 4) * sigma * 1e-2)).astype(np.float32)
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(c)), k)
+    got, st = _refine3(p32, a32, pmid, p16, a16, paths, k)
+    assert got == want, st
+    assert st["tiers"] == 3 and st["eps_mid"] <= st["eps"] and st["rows_exact"] <= st["rows_mid"] + st["calibration_rows"]
+    got2, st2 = _refine(p32, a32, p16, a16, paths, k)
+    assert got2 == want and st2["tiers"] == 2
+
+
+def test_three_tiers_on_the_bench_shape_send_most_marked_rows_to_the_middle_tier():
+    from oracle import cbind
+    p32, a32, p16, a16, paths = _pool(20000, 47, 0.3, 2e-3, 9, dominant=True)
+    r = np.random.RandomState(1)
+    pmid = (p32.astype(np.float64) * (1.0 + np.clip(r.randn(*p32.shape), -4, 4) * 6e-6)).astype(np.float32)
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(47)), 16)
+    got, st = _refine3(p32, a32, pmid, p16, a16, paths, 16)
+    assert got == want
+    non_calib_exact = st["rows_exact"] - st["calibration_rows"]
+    assert non_calib_exact < 0.35 * st["rows_mid"], st          # the f32 tower re-encodes a fraction of what the middle tier does
+    assert st["audit_rows"] > 0 and not st["audit_widened"] and st["unverified_rows"] == 20000 - st["rows_refined"]
+
+
+def test_the_audit_catches_an_understated_bound():
+    """Calibration rows are quiet; one row in six deviates 30x more and nothing the scan decides touches those rows (near-uniform rows far
+    below every board: rejected by their own class, their spill certainly irrelevant), so without the audit the loop ends on the quiet
+    bound with those rows taken on trust.  The audit's sample hits them: a deviation beyond the bound (`audit_widened`), the bound is
+    widened to cover it and the scan repeats."""
+    from oracle import cbind
+    n, c, k = 6000, 8, 4
+    r = np.random.RandomState(3)
+    cal = set(np.unique(np.linspace(0, n - 1, 256).astype(np.int64)).tolist())
+    noisy = np.array([i % 6 == 1 and i not in cal for i in range(n)])
+    lg = r.randn(n, c) * 2.5
+    lg[noisy] *= 0.01
+    z = np.exp(lg - lg.max(1, keepdims=True))
+    p32 = (z / z.sum(1, keepdims=True)).astype(np.float32)
+    p16 = (p32.astype(np.float64) * (1.0 + np.clip(r.randn(n, c), -5, 5) * 1e-4)).astype(np.float32)
+    p16[noisy] = (p32[noisy].astype(np.float64) * (1.0 + r.uniform(-1, 1, (int(noisy.sum()), c)) * 3e-3)).astype(np.float32)
+    a32, a16 = p32.argmax(1).astype(np.int32), p16.argmax(1).astype(np.int32)
+    paths = [f"p/{(i * 7919) % 100000:05d}_{i}.jpg" for i in range(n)]
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(c)), k)
+    got0, st0 = _refine(p32, a32, p16, a16, paths, k, audit=0)
+    assert st0["audits"] == 0 and st0["eps"] < 1.5e-3 and st0["unverified_rows"] > 5000      # the quiet bound, noisy rows never looked at
+    got, st = _refine(p32, a32, p16, a16, paths, k)
+    assert st["audit_widened"] and st["audits"] >= 2 and st["eps"] >= 2e-3 and st["audit_max_deviation"] >= 1.5e-3, st
+    assert got == want and got0 == want          # (here the understated bound happened to be harmless; the audit cannot know that)
+
+
+def test_denormal_probabilities_are_covered_by_the_absolute_slack():
+    """Peaked rows: most probabilities underflow towards 0, where a relative bound says nothing (an f16-tower value of 0 against a true
+    1e-42).  The scan's intervals carry an absolute slack there, so comparisons among such values are undecidable until the rows are
+    exact, and the deviation measure ignores pairs inside the slack instead of dividing by them."""
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    from oracle import cbind
+    r = np.random.RandomState(5)
+    n, c, k = 400, 6, 3
+    lg = (r.randn(n, c) * 40).astype(np.float32)
+    z = np.exp((lg - lg.max(1, keepdims=True)).astype(np.float64))
+    p32 = (z / z.sum(1, keepdims=True)).astype(np.float32)                  # many entries are denormal or exactly 0
+    assert (p32 == 0).any() and ((p32 > 0) & (p32 < 1e-38)).any()
+    p16 = (p32.astype(np.float64) * (1.0 + r.randn(n, c) * 1e-3)).astype(np.float32)
+    p16[p32 < 1e-35] = 0.0                                                   # the screen flushes what the exact tower still resolves
+    a32, a16 = p32.argmax(1).astype(np.int32), p16.argmax(1).astype(np.int32)
+    paths = [f"p/{(i * 7919) % 100000:05d}_{i}.jpg" for i in range(n)]
+    assert pl._deviation(p16, p32, pl.REFINE_ABS_EPS) < 1e-2                # flushed pairs do not count as infinite deviations
+    assert pl._deviation(np.float32([0.0]), np.float32([1e-20]), pl.REFINE_ABS_EPS) == np.inf
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(c)), k)
+    got, st = _refine(p32, a32, p16, a16, paths, k)
+    assert got == want, st
+
+
+def test_deviation_is_relative_to_the_smaller_value():
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    assert abs(pl._deviation(np.float32([0.5]), np.float32([1.0]), 0.0) - 1.0) < 1e-6      # |1 - 0.5| / 0.5: the scan's interval is around the APPROXIMATE value
+    assert abs(pl._deviation(np.float32([1.0]), np.float32([0.5]), 0.0) - 1.0) < 1e-6
