@@ -122,8 +122,9 @@ class Loop:
         self.graphed = steps.GraphedCoopStep(self.model, self.m, self.opt) if args.graph else None
         self.graphed_f = steps.GraphedCoopFeatureStep(self.model, self.m, self.opt) if args.graph else None
         self.twin = self.m.exact_twin() if args.mode == "identical" else None
+        self.split = self.m.split_twin() if args.mode == "identical" and os.environ.get("GRIP_SPLIT_TIER", "auto") != "0" else None     # the middle tier (precision 2)
         self.refine_stats = None
-        self.stage = {k: 0.0 for k in ("encode_f16", "allgather", "head_scan", "refine_exact", "train")}     # wall seconds per stage, this rank
+        self.stage = {k: 0.0 for k in ("encode_f16", "allgather", "head_scan", "refine_split", "refine_exact", "train")}     # wall seconds per stage, this rank
         self.t_pl = self.t_tr = 0.0
         self.m_selected = 0
         self.train_steps = 0
@@ -152,27 +153,30 @@ class Loop:
             _, probs, _, am_p = engine.cosine_head(emb, txt, scale)
             probs_h, pred_h = probs.cpu().numpy(), am_p.cpu().numpy()
             lo = self.rank * a.pool
-            tower32 = self.twin.visual.tower
-            t_exact = [0.0]
+            t_tier = {"exact": 0.0, "split": 0.0}
 
-            def exact_rows(idx):
-                ta = time.perf_counter()
-                mine = torch.from_numpy(idx[(idx >= lo) & (idx < lo + a.pool)] - lo).to(self.device)
-                rows = torch.empty(len(mine), self.d.embed_dim, dtype=torch.float32, device=self.device)
-                if len(mine):
-                    tower32.encode_chunks(lambda s, e: self.pool[mine[s:e]], rows, 0, len(mine), a.exact_chunk, streams=1)
-                rows = gdist.allgather_selected(rows, idx, self.n_total)
-                _, p, _, ap = engine.cosine_head(rows, txt, scale)
-                out = p.cpu().numpy(), ap.cpu().numpy()
-                t_exact[0] += time.perf_counter() - ta
-                return out
+            def rows_through(tower, tier, chunk):
+                def rows(idx):
+                    ta = time.perf_counter()
+                    mine = torch.from_numpy(idx[(idx >= lo) & (idx < lo + a.pool)] - lo).to(self.device)
+                    emb_rows = torch.empty(len(mine), self.d.embed_dim, dtype=torch.float32, device=self.device)
+                    if len(mine):
+                        tower.encode_chunks(lambda s, e: self.pool[mine[s:e]], emb_rows, 0, len(mine), chunk, streams=1)
+                    emb_rows = gdist.allgather_selected(emb_rows, idx, self.n_total)
+                    _, p, _, ap = engine.cosine_head(emb_rows, txt, scale)
+                    out = p.cpu().numpy(), ap.cpu().numpy()
+                    t_tier[tier] += time.perf_counter() - ta
+                    return out
+                return rows
 
-            img, cls, self.refine_stats = pl.refine_scan(probs_h, pred_h, self.ranks, self.k, exact_rows)
+            img, cls, self.refine_stats = pl.refine_scan(probs_h, pred_h, self.ranks, self.k, rows_through(self.twin.visual.tower, "exact", a.exact_chunk),
+                                                         mid_rows=rows_through(self.split.visual.tower, "split", a.exact_chunk) if self.split is not None else None)
             t3 = self.tick()
         st["encode_f16"] += t1 - t0
         st["allgather"] += t2 - t1
-        st["refine_exact"] += t_exact[0]
-        st["head_scan"] += t3 - t2 - t_exact[0]
+        st["refine_exact"] += t_tier["exact"]
+        st["refine_split"] += t_tier["split"]
+        st["head_scan"] += t3 - t2 - t_tier["exact"] - t_tier["split"]
         return img, cls
 
     def pseudolabel_pass(self, model, streams):
@@ -269,7 +273,7 @@ N_SLOTS = 144   # slot = variant * 16 + epilogue id (csrc/gemm.hip)
 
 def kname(slot):
     v, e = divmod(slot, 16)
-    return {0: f"gemm_f32_kernel<{e}>", 1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
+    return {0: f"gemm_f32_kernel<{e}>", 7: f"gemm_split_kernel<{e}>", 1: f"gemm_f16_kernel<{e}, 4>", 4: f"gemm_f16_kernel<{e}, 2>", 2: f"gemm_big_kernel<{e}, 256, 256, 4>", 3: f"gemm_big_kernel<{e}, 256, 128, 3>",
             5: f"gemm_k64_kernel<{e}, 8, 8>", 6: f"gemm_k64p_kernel<{e}>", 8: f"gemm_k64_kernel<{e}, 8, 6>"}.get(v, f"gemm?<{e}>") + f" [{EPI_NAMES[e] if e < len(EPI_NAMES) else e}]"
 
 

@@ -28,6 +28,13 @@ int grip_debug_gemm_splitk(const void* A, const void* W, int M, int N, int K, fl
  * rowstat [M, 2] = (mean, rstd) from the [M, parts, 2] partial sums over rows of width d. */
 int grip_debug_ln_fold(const void* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* colsum, float* bias_out,
                        int N, int K, const float* stat_part, int parts, float* rowstat, int M, int d, void* stream);
+/* The split-f16 GEMM of precision-2 towers (csrc/gemm_split.hip) on f32 inputs: A [m_pad, K] and W [N, K] are rewritten in the split layout
+ * ([32 x hi | 32 x lo'] f16 per 32 consecutive k) into the scratch buffers a_split / w_split (4 bytes per element), then out = epi(A W^T):
+ * epi 0 f32, 1 +bias -> f32, 3 +bias +resid(f32) -> f32, 2 +bias, QuickGELU -> the split layout (4 bytes per element).  m_pad: rows of A
+ * allocated, a multiple of 256.  grip_debug_split_rows: f32 rows -> the split layout. */
+int grip_debug_gemm_split(int epi, const float* A, const float* W, int M, int N, int K, const float* bias, const float* resid, void* out,
+                          void* a_split, void* w_split, int m_pad, void* stream);
+int grip_debug_split_rows(const float* x, void* out, int64_t rows, int K, void* stream);
 /* out[B*S, H*64] = softmax(q k^T / 8 [+ causal mask]) v for qkv[B*S, 3*H*64] (f16). */
 int grip_debug_attention(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
 /* The same in f32 (exact mode, csrc/attention_f32.hip): qkv and out f32, any S. */

@@ -95,6 +95,7 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
     d = _cfg.get_dims(name)
     if exact is None:
         exact = os.environ.get("GRIP_EXACT", "0") == "1"
+    exact = int(exact)          # 2 = split-f16 towers (developer / tests: the middle tier on its own)
     m = CLIP(d, device, exact=exact)
     path = os.environ.get("CLIP_WEIGHTS")
     if path:
@@ -114,11 +115,12 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
     if not exact:
         src = None if path is None else sd       # a checkpoint's tensors are kept for the twin; the synthetic init is regenerated
 
-        def build_twin():
-            t = CLIP(d, device, exact=True)
+        def build_twin(precision=1):
+            t = CLIP(d, device, exact=precision)
             load_openai_state_dict(t, src if src is not None else {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed).items()})
             return t
         m._twin[1] = build_twin
+        m._split[1] = lambda: build_twin(2)
     return m, _preprocess(d.image_resolution, device)
 
 

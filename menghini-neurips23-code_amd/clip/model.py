@@ -110,7 +110,8 @@ class CLIP(_TowerModule):
     def __init__(self, d: ClipDims, device="cuda", exact=False):
         super().__init__()
         self.dims = d
-        self.exact = bool(exact)   # f32 towers (comparison mode): `dtype` is float32, like the reference's clip.load on a CPU
+        self.precision = int(exact)        # 0 f16 towers, 1 f32 towers, 2 split-f16 towers (include/grip_amd.h: grip_dims.precision)
+        self.exact = self.precision == 1   # f32 towers (comparison mode): `dtype` is float32, like the reference's clip.load on a CPU
         self.context_length = d.context_length
         self.vocab_size = d.vocab_size
         self.visual = VisionTransformer(d, device, exact=exact)
@@ -118,6 +119,7 @@ class CLIP(_TowerModule):
         self._bind(engine.text_tower(d, device, exact=exact))
         self.logit_scale = _frozen(torch.ones([], device=device) * math.log(1 / 0.07))
         self._twin = [None, None]       # [the exact (f32) twin, a callable that builds it]: set by clip.load, out of nn.Module's registry
+        self._split = [None, None]      # the same for the split-f16 twin
 
     def exact_twin(self):
         """The same model with f32 towers (weights from the same checkpoint, NOT re-derived from this model's f16 blobs): what
@@ -129,6 +131,16 @@ class CLIP(_TowerModule):
                 raise engine.native.GripError("this CLIP was not created by clip.load: no source for its exact twin")
             self._twin[0] = self._twin[1]()
         return self._twin[0]
+
+    def split_twin(self):
+        """The same model with split-f16 towers (precision 2: every GEMM operand carried as an f16 hi / lo pair, three f16 MFMA products,
+        f32 everywhere else): the MIDDLE tier of the screen-and-refine pseudolabel pass -- probabilities within ~1e-5 of the f32 twin's at
+        several times its throughput.  None when the model has no source for it (pseudolabels.mid_tower decides whether a pool uses it)."""
+        if self.precision != 0 or self._split[1] is None:
+            return None
+        if self._split[0] is None:
+            self._split[0] = self._split[1]()
+        return self._split[0]
 
     @property
     def text_tower(self):

@@ -12,7 +12,7 @@
 
 #include "common.h"
 
-template <bool CAUSAL>
+template <bool CAUSAL, bool SPLIT = false>     // SPLIT: `out` in the split layout of gemm_split.hip (precision-2 towers: it feeds the out-proj GEMM)
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int H, int qblocks) {
     __shared__ f32x4 Ks[32][16];
     __shared__ f32x4 Vs[32][16];
@@ -80,16 +80,25 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
         m = mn;
     }
     if (qi < S) {
-        f32x4* op = (f32x4*)(out + ((size_t)b * S + qi) * D + h * 64);
+        if constexpr (SPLIT) {
+            const SplitRow r{(half_t*)out + ((size_t)b * S + qi) * 2 * D};
 #pragma unroll
-        for (int c = 0; c < 16; ++c) op[c] = o[c] / l;
+            for (int c = 0; c < 16; ++c) store4(r, h * 16 + c, o[c] / l);
+        } else {
+            f32x4* op = (f32x4*)(out + ((size_t)b * S + qi) * D + h * 64);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) op[c] = o[c] / l;
+        }
     }
 }
 
-int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s) {
+int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s, int split_out) {
     GRIP_REQUIRE(S >= 1 && B >= 1 && H >= 1, "attention_f32: bad shape B=%d S=%d H=%d", B, S, H);
     const int qblocks = (S + 255) / 256;
-    if (causal)
+    if (split_out) {
+        if (causal) hipLaunchKernelGGL((attn_fwd_f32_kernel<true, true>), dim3(B * H * qblocks), dim3(256), 0, s, qkv, out, S, H, qblocks);
+        else hipLaunchKernelGGL((attn_fwd_f32_kernel<false, true>), dim3(B * H * qblocks), dim3(256), 0, s, qkv, out, S, H, qblocks);
+    } else if (causal)
         hipLaunchKernelGGL(attn_fwd_f32_kernel<true>, dim3(B * H * qblocks), dim3(256), 0, s, qkv, out, S, H, qblocks);
     else
         hipLaunchKernelGGL(attn_fwd_f32_kernel<false>, dim3(B * H * qblocks), dim3(256), 0, s, qkv, out, S, H, qblocks);

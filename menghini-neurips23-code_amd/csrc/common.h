@@ -112,6 +112,24 @@ __device__ __forceinline__ f32x4 load4(const half_t* p, int i) {
 }
 __device__ __forceinline__ void store4(float* p, int i, f32x4 v) { ((f32x4*)p)[i] = v; }
 __device__ __forceinline__ void store4(half_t* p, int i, f32x4 v) { ((half4*)p)[i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
+// Split layout of the precision-2 tier (gemm_split.hip): per row and 32 consecutive columns one 128-byte line [32 x hi | 32 x lo'],
+// hi = f16(x), lo' = f16((x - hi) * 2^11).  SplitRow tags an output row pointer of that layout for store4.
+struct SplitRow { half_t* p; };
+__device__ __forceinline__ void split_f16x4(f32x4 v, half4& hi, half4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const half_t h = (half_t)v[e];
+        hi[e] = h;
+        lo[e] = (half_t)((v[e] - (float)h) * 2048.0f);
+    }
+}
+__device__ __forceinline__ void store4(SplitRow r, int i, f32x4 v) {       // columns 4 i .. 4 i + 3 of the row
+    half4 hi, lo;
+    split_f16x4(v, hi, lo);
+    half_t* o = r.p + (i >> 3) * 64 + (i & 7) * 4;
+    *(half4*)o = hi;
+    *(half4*)(o + 32) = lo;
+}
 
 // The LayerNorm arithmetic is compiled with floating-point contraction OFF: it is inlined into several kernels (stand-alone,
 // gather, sequence assembly) and every one of them must round identically whatever the surrounding code lets the
@@ -153,6 +171,7 @@ struct GemmArgs {
     int ldc;
     float scalar;
     int f32;            // 1 = exact mode: A, W, resid and every activation output are f32 (gemm_f32.hip, v_mfma_f32_16x16x4_f32)
+                        // 2 = split-f16 tier: A and W in the split layout, resid / bias / output f32 (gemm_split.hip)
     // LayerNorm statistics travelling with the residual stream (f16 towers):
     float* stat_part;      // EPI_BIAS_RESID, optional: [N/64, M, 2] per-row partial (sum, sum of squares) of the values written, one pair
                            // per 64-column wave tile; ln_stats_finalize turns them into rowstat for the consuming GEMM
@@ -172,8 +191,13 @@ int gemm_pick_ksplit(int M, int N, int K);
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);
+// split-f16 tier (gemm_split.hip; GemmArgs.f32 == 2): A and W in the split layout ([32 x hi | 32 x lo'] f16 per 32 consecutive k, row pitch
+// 4 K bytes), f32 bias / residual / output -- EPI_BIAS_GELU_F16 writes its output in the split layout (it feeds the next split GEMM)
+int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s);
+int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s);
 
-// Activation buffers are f16 (default) or f32 (exact mode): the row kernels take untyped pointers plus the flag.
+// Activation buffers are f16 (default) or f32 (exact mode): the row kernels take untyped pointers plus the flag.  f32 == 2 (split-f16
+// tier): inputs f32 as in exact mode; launch_layernorm_f16 writes its OUTPUT (a GEMM operand) in the split layout of gemm_split.hip.
 // row-wise kernels (rowops.hip)
 int launch_im2col(const void* images, int images_f16, void* out, int out_f32, int B, int R, int patch, int Kpad, hipStream_t s);
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
@@ -210,7 +234,8 @@ int launch_gather_rows(const half_t* x, const int32_t* row_index, int row_stride
 // backward of launch_attention_row: o_rows / do_rows [B, H*64] (the forward's output rows and their gradient) -> the whole packed dqkv [B, S, 3, H*64]
 int launch_attention_row_bwd(const half_t* qkv, const half_t* o_rows, const half_t* do_rows, const int32_t* row_index, half_t* dqkv, int B, int S, int H, int causal,
                              hipStream_t s);
-int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s);
+// split_out != 0: `out` is written in the split layout of gemm_split.hip (it feeds the out-proj GEMM of a precision-2 tower)
+int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s, int split_out = 0);
 // shared_rows > 0: shared-prefix layout; kv_part [B, shared_rows, 2, H*64] f32 scratch for the per-sequence dK / dV of the shared keys
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s,
                          int shared_rows = 0, float* kv_part = nullptr);

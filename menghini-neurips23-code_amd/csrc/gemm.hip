@@ -1919,6 +1919,10 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     static const int rot_m = getenv("GRIP_KROT_M") ? atoi(getenv("GRIP_KROT_M")) : 0;
     GemmArgs a = a_in;
     a.rot_rows = (a.rot_rows && !a.f32 && rot_m >= 0) ? (rot_m > 0 ? rot_m : (a.ksplit > 1 ? 1 : 2)) : 0;
+    if (a.f32 == 2) {   // split-f16 tier (gemm_split.hip); profiler variant 7
+        *chosen = 7;
+        return launch_gemm_split(epi, a, s);
+    }
     if (a.f32) {        // exact mode: f32 operands (gemm_f32.hip); profiler variant 0
         *chosen = 0;
         return launch_gemm_f32(epi, a, s);

@@ -8,7 +8,7 @@
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over rows of x (residual stream, f16; or f32 for the test hook) -> f16.  row_index == null: row r reads x[r]; else row r reads
 // x[r * row_stride + row_index[r]] (EOT gather); row_stride alone gathers x[r * row_stride] (CLS).
-template <int NV, typename XT, typename OT = half_t>
+template <int NV, typename XT, typename OT = half_t, bool SPLIT = false>       // SPLIT: OT = half_t, rows written in the split layout (common.h)
 __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      OT* __restrict__ out, int n_rows, int d) {
@@ -24,7 +24,11 @@ __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, c
         if (lane + 64 * i < d4) v[i] = load4(xr, lane + 64 * i);
     float mean, rstd;
     ln_normalize<NV>(v, lane, d4, d, mean, rstd);
-    OT* o = out + (size_t)row * d;
+    auto orow = [&]() {
+        if constexpr (SPLIT) return SplitRow{(half_t*)out + (size_t)row * 2 * d};
+        else return out + (size_t)row * d;
+    };
+    const auto o = orow();
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
@@ -48,7 +52,10 @@ __global__ __launch_bounds__(256) void ln_f16_kernel(const XT* __restrict__ x, c
     } while (0)
 
 int launch_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int f32, int M, int d, hipStream_t s) {
-    if (f32) {
+    if (f32 == 2) {
+        GRIP_REQUIRE(d % 32 == 0, "layernorm (split layout): width %d %% 32 != 0", d);
+        DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, float, half_t, true>), dim3((M + 3) / 4), dim3(256), 0, s, (const float*)x, (const int32_t*)nullptr, 1, gamma, beta, (half_t*)out, M, d));
+    } else if (f32) {
         DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, float, float>), dim3((M + 3) / 4), dim3(256), 0, s, (const float*)x, (const int32_t*)nullptr, 1, gamma, beta, (float*)out, M, d));
     } else {
         DISPATCH_NV(d, hipLaunchKernelGGL((ln_f16_kernel<NV, resid_t>), dim3((M + 3) / 4), dim3(256), 0, s, (const resid_t*)x, (const int32_t*)nullptr, 1, gamma, beta, (half_t*)out, M, d));

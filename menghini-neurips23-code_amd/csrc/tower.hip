@@ -34,6 +34,7 @@ struct LayerW {
     int64_t in_w, out_w, fc_w, proj_w;          // [3d,d] [d,d] [4d,d] [d,4d]
     int64_t in_wT, out_wT, fc_wT, proj_wT;      // derived transposes: [d,3d] [d,d] [d,4d] [4d,d]
     int64_t in_wG, fc_wG;                       // derived: LayerNorm-folded operands f16(gamma o W) of the QKV and c_fc GEMMs
+    int64_t in_wS = -1, out_wS = -1, fc_wS = -1, proj_wS = -1;   // derived, precision 2 only: the four weights in the split layout of gemm_split.hip
     // f32
     int64_t ln1_g, ln1_b, in_b, out_b, ln2_g, ln2_b, fc_b, proj_b;
     int64_t in_cs, in_bb, fc_cs, fc_bb;         // derived: colsum(W') and W beta + b of the two folded GEMMs
@@ -113,6 +114,12 @@ static int build_layout(const grip_dims& D, Layout& L) {
         w.in_bb = add_slot(L, p + "attn.in_proj#bias", 1, 1, 1, 3 * d);
         w.fc_cs = add_slot(L, p + "mlp.c_fc#colsum", 1, 1, 1, 4 * d);
         w.fc_bb = add_slot(L, p + "mlp.c_fc#bias", 1, 1, 1, 4 * d);
+        if (D.precision == 2) {     // [N, K/32, 32 hi | 32 lo'] f16: as many bytes as the f32 matrix (the operand blob has f32 elements)
+            w.in_wS = add_slot(L, p + "attn.in_proj_weight#S", 0, 1, 3 * d, d);
+            w.out_wS = add_slot(L, p + "attn.out_proj.weight#S", 0, 1, d, d);
+            w.fc_wS = add_slot(L, p + "mlp.c_fc.weight#S", 0, 1, 4 * d, d);
+            w.proj_wS = add_slot(L, p + "mlp.c_proj.weight#S", 0, 1, d, 4 * d);
+        }
     }
     const char* lnf = D.kind == 0 ? "ln_post" : "ln_final";
     L.lnpost_g = add_slot(L, std::string(lnf) + ".weight", 1, 0, 1, d);
@@ -207,7 +214,9 @@ struct grip_tower {
     Layout L;
     half_t* w16;      // GEMM-operand blob: f16, or f32 when f32 != 0 (exact mode) -- always addressed through wop()
     float* w32;
-    int f32 = 0;      // dims.precision: 0 = f16 operands / f16 residual stream, 1 = f32 everywhere (comparison mode, inference only)
+    int f32 = 0;      // dims.precision != 0: activations, residual stream, attention and the operand blob's primary slots are f32 (inference only)
+    int split = 0;    // dims.precision == 2: the four GEMMs of a block run on the split-f16 kernel (gemm_split.hip); their A operands are written in
+                      // its layout by the producers (LayerNorm, f32 attention, GELU epilogue), their weights by grip_tower_finalize (#S slots)
     uint64_t generation = 0;   // counts train-mode forwards (see `pending`)
     const void* wop(int64_t elem_off) const { return (const char*)w16 + elem_off * (f32 ? 4 : 2); }
     void* wop(int64_t elem_off) { return (char*)w16 + elem_off * (f32 ? 4 : 2); }
@@ -319,8 +328,9 @@ extern "C" int grip_tower_create(const grip_dims* dims, void* f16_blob, void* f3
     try {
         grip_tower* t = new grip_tower();
         t->D = *dims;
-        if (dims->precision != 0 && dims->precision != 1) { delete t; GRIP_REQUIRE(false, "dims.precision must be 0 (f16) or 1 (f32 exact)"); }
-        t->f32 = dims->precision;
+        if (dims->precision < 0 || dims->precision > 2) { delete t; GRIP_REQUIRE(false, "dims.precision must be 0 (f16), 1 (f32 exact) or 2 (split f16)"); }
+        t->f32 = dims->precision != 0;
+        t->split = dims->precision == 2;
         int rc = build_layout(*dims, t->L);
         if (rc) { delete t; return rc; }
         t->w16 = (half_t*)f16_blob;
@@ -353,6 +363,13 @@ extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
             float* F = t->w32;
             if ((rc = launch_ln_fold_weights(t->w16 + w.in_w, F + w.ln1_g, F + w.ln1_b, F + w.in_b, t->w16 + w.in_wG, F + w.in_cs, F + w.in_bb, 3 * d, d, s))) return rc;
             if ((rc = launch_ln_fold_weights(t->w16 + w.fc_w, F + w.ln2_g, F + w.ln2_b, F + w.fc_b, t->w16 + w.fc_wG, F + w.fc_cs, F + w.fc_bb, 4 * d, d, s))) return rc;
+        }
+    if (t->split)   // split-layout copies of the block weights (the f32 originals stay: patch embedding and the final projection use them)
+        for (const LayerW& w : t->L.layer) {
+            if ((rc = launch_split_rows((const float*)t->wop(w.in_w), t->wop(w.in_wS), 3 * d, d, d, s))) return rc;
+            if ((rc = launch_split_rows((const float*)t->wop(w.out_w), t->wop(w.out_wS), d, d, d, s))) return rc;
+            if ((rc = launch_split_rows((const float*)t->wop(w.fc_w), t->wop(w.fc_wS), 4 * d, d, d, s))) return rc;
+            if ((rc = launch_split_rows((const float*)t->wop(w.proj_w), t->wop(w.proj_wS), d, 4 * d, 4 * d, s))) return rc;
         }
     if ((rc = launch_transpose(t->wop(t->L.proj), t->wop(t->L.projT), f, d, t->D.embed_dim, t->D.embed_dim, s))) return rc;
     t->finalized = true;
@@ -387,6 +404,7 @@ extern "C" int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix
 // Exact (f32) towers keep the literal LayerNorm -> GEMM sequence.
 static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, const int32_t* read_rows, hipStream_t s, resid_t** x_final, bool* compact) {
     const int d = t->D.width, H = t->D.heads, f = t->f32;
+    const int gf = t->split ? 2 : f;      // GemmArgs.f32 of the four block GEMMs, and the output layout of what feeds them
     const float* F = t->w32;
     resid_t* x = x0;
     const int parts = d / 64;
@@ -466,10 +484,10 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         GemmArgs a{};
         a.rot_rows = w.train;     // train-mode GEMMs may stagger their K walks by tile row (common.h)
         if (!fold) {
-            RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, f, w.M, d, s));
-            a.f32 = f; a.A = w.xn; a.W = t->wop(lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
+            RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, gf, w.M, d, s));
+            a.f32 = gf; a.A = w.xn; a.W = t->wop(t->split ? lw.in_wS : lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_BIAS_F16, a, s));
-            if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s));
+            if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s, t->split));
             else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s, w.Ps));
         } else {
             a.A = x; a.W = t->w16 + lw.in_wG; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_bb; a.colsum = F + lw.in_cs; a.rowstat = w.rowstat;
@@ -479,14 +497,14 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         }
         a = GemmArgs{};
         a.rot_rows = w.train;
-        a.f32 = f; a.A = att; a.W = t->wop(lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
+        a.f32 = gf; a.A = att; a.W = t->wop(t->split ? lw.out_wS : lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
         a.stat_part = fold ? w.stat_part : nullptr;
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         a = GemmArgs{};
         a.rot_rows = w.train;
         if (!fold) {
-            RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, f, w.M, d, s));
-            a.f32 = f; a.A = w.xn; a.W = t->wop(lw.fc_w); a.bias = F + lw.fc_b;
+            RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, gf, w.M, d, s));
+            a.f32 = gf; a.A = w.xn; a.W = t->wop(t->split ? lw.fc_wS : lw.fc_w); a.bias = F + lw.fc_b;
         } else {
             RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
             a.A = x_mid; a.W = t->w16 + lw.fc_wG; a.bias = F + lw.fc_bb; a.colsum = F + lw.fc_cs; a.rowstat = w.rowstat;
@@ -496,7 +514,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         RUN(launch_gemm(fold ? EPI_LNFOLD_GELU_F16 : EPI_BIAS_GELU_F16, a, s));
         a = GemmArgs{};
         a.rot_rows = w.train;
-        a.f32 = f; a.A = w.h; a.W = t->wop(lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
+        a.f32 = gf; a.A = w.h; a.W = t->wop(t->split ? lw.proj_wS : lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
         a.stat_part = (!fold || last) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         if (fold && !last) RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
@@ -627,6 +645,21 @@ extern "C" int grip_debug_ln_fold(const void* W, const float* gamma, const float
     int rc = launch_ln_fold_weights((const half_t*)W, gamma, beta, bias, (half_t*)Wg, colsum, bias_out, N, K, (hipStream_t)stream);
     if (rc || !stat_part) return rc;
     return launch_ln_stats_finalize(stat_part, parts, rowstat, M, d, (hipStream_t)stream);
+}
+// Split-f16 GEMM (gemm_split.hip) on f32 inputs: A [m_pad, K] and W [N, K] are first rewritten in the split layout into the caller's scratch
+// buffers a_split / w_split (4 bytes per element each), then out = epi(A W^T) -- f32, or the split layout for epi 2 (out: 4 bytes per element).
+extern "C" int grip_debug_gemm_split(int epi, const float* A, const float* W, int M, int N, int K, const float* bias, const float* resid, void* out,
+                                     void* a_split, void* w_split, int m_pad, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    RUN(launch_split_rows(A, a_split, m_pad, K, K, s));
+    RUN(launch_split_rows(W, w_split, N, K, K, s));
+    GemmArgs a{};
+    a.f32 = 2; a.A = a_split; a.W = w_split; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid; a.out = out; a.ldc = N;
+    return launch_gemm(epi, a, s);
+}
+// f32 rows -> the split layout (out: 4 bytes per element), e.g. to read a split-layout result back on the host side of a test
+extern "C" int grip_debug_split_rows(const float* x, void* out, int64_t rows, int K, void* stream) {
+    return launch_split_rows(x, out, rows, K, K, (hipStream_t)stream);
 }
 extern "C" int grip_debug_attention_exact(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
     return launch_attention_fwd_f32((const float*)qkv, (float*)out, B, S, H, causal, (hipStream_t)stream);

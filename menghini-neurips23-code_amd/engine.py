@@ -64,8 +64,9 @@ class Tower:
                  max_prefix=64, device="cuda", exact=False):
         self.device = require_gpu(device)
         self.lib = native.lib()
-        self.exact = bool(exact)     # f32 weights / activations / attention (comparison mode, inference only)
-        self.dims = native.Dims(kind, width, layers, heads, embed_dim, seq0, patch, resolution, vocab, max_prefix, int(self.exact))
+        self.precision = int(exact)  # grip_dims.precision: 0 f16 towers, 1 f32 (exact comparison mode), 2 split-f16 (the middle tier of screen-and-refine)
+        self.exact = self.precision != 0     # f32 weights / activations / attention: inference only
+        self.dims = native.Dims(kind, width, layers, heads, embed_dim, seq0, patch, resolution, vocab, max_prefix, self.precision)
         self.kind, self.width, self.embed_dim, self.seq0 = kind, width, embed_dim, seq0
         n16, n32 = c_int64(), c_int64()
         native.check(self.lib.grip_layout_size(byref(self.dims), byref(n16), byref(n32)))

@@ -384,7 +384,8 @@ class TrainingStrategy:
             twin = self.clip_model.exact_twin()
             txt, vprompt = self.trained_text_features(classes, twin)
             fp, lab = pl.identical_lists(self.clip_model.visual.tower, twin.visual.tower, images, txt, self.scale(),
-                                         list(unlabeled_data.filepaths), labels, k, chunk=440, prefix=vprompt, argmax_on="logits")
+                                         list(unlabeled_data.filepaths), labels, k, chunk=440, prefix=vprompt, argmax_on="logits",
+                                         visual_mid=pl.mid_tower(self.clip_model, len(unlabeled_data.filepaths)))
         else:
             img, txt = self.trained_features(images, classes)
             fp, lab = pl.pseudolabel_from_features(img, txt, self.scale(), list(unlabeled_data.filepaths), labels, k, argmax_on="logits")

@@ -94,6 +94,8 @@ _DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of
     "grip_profile_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "grip_debug_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "grip_debug_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "grip_debug_gemm_split": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "grip_debug_split_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

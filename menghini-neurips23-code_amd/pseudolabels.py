@@ -301,6 +301,20 @@ def mode():
     return m
 
 
+SPLIT_TIER_MIN_ROWS = 4096      # pools below this go straight from the f16 screen to the f32 tower (the split twin costs HBM and a build)
+
+
+def mid_tower(clip_model, n_rows):
+    """The vision tower of `clip_model`'s split-f16 twin when the middle tier pays for a pool of `n_rows` rows, else None.
+    $GRIP_SPLIT_TIER: "auto" (default: pools of >= SPLIT_TIER_MIN_ROWS rows), "1" always, "0" never."""
+    import os
+    want = os.environ.get("GRIP_SPLIT_TIER", "auto")
+    if want == "0" or (want == "auto" and n_rows < SPLIT_TIER_MIN_ROWS) or not hasattr(clip_model, "split_twin"):
+        return None
+    twin = clip_model.split_twin()
+    return None if twin is None else twin.visual.tower
+
+
 def take_images(images, idx):
     """Rows `idx` (ascending int64 array) of an image pool: a tensor [N,3,R,R] or a lazy pool with .take(idx)."""
     if torch.is_tensor(images):

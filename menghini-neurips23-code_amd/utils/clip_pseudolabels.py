@@ -80,9 +80,10 @@ def compute_pseudo_labels(k, template, dataset, classnames, transform, clip_mode
         with torch.no_grad():
             txt = twin.encode_text(text)                                       # once, not once per image
         new_imgs, new_labels = pl.identical_lists(clip_model.visual.tower, twin.visual.tower, images, txt, scale, list(dataset.filepaths),
-                                                  class_labels, k, chunk=chunk, argmax_on="probs")
+                                                  class_labels, k, chunk=chunk, argmax_on="probs", visual_mid=pl.mid_tower(clip_model, len(dataset.filepaths)))
         st = pl.LAST_REFINE_STATS
-        log.info(f"screen and refine: {st['rows_refined']} of {st['rows']} rows re-encoded exactly in {st['rounds']} rounds (bound {st['eps']:.2e})")
+        log.info(f"screen and refine: {st['rows_refined']} of {st['rows']} rows re-encoded ({st['rows_mid']} split-f16, {st['rows_exact']} f32) in {st['rounds']} rounds "
+                 f"(bound {st['eps']:.2e}; audit {st['audit_rows']} rows, largest deviation {st['audit_max_deviation']:.2e})")
     else:
         with torch.no_grad():
             txt = clip_model.encode_text(text)                                 # once, not once per image

@@ -111,9 +111,9 @@ CASES = {
         ("image", "methods/unsupervised_learning/visual_fpl.py", "methods.unsupervised_learning", "VisualPrompt", "VisualFPL", 6, 40, 31, 5, 4, 902),
     ],
     "vitb16": [
-        ("multi", "methods/transductive_zsl/multimodal_fpl.py", "methods.transductive_zsl", "MultimodalPrompt", "MultimodalFPL", 5, 14, 41, 6, 4, SEED),
-        ("text", "methods/semi_supervised_learning/textual_fpl.py", "methods.semi_supervised_learning", "TextualPrompt", "TextualFPL", 5, 14, 43, 4, 16, SEED),
-        ("image", "methods/unsupervised_learning/visual_fpl.py", "methods.unsupervised_learning", "VisualPrompt", "VisualFPL", 5, 14, 47, 3, 16, SEED),
+        ("multi", "methods/transductive_zsl/multimodal_fpl.py", "methods.transductive_zsl", "MultimodalPrompt", "MultimodalFPL", 5, 14, 41, 6, 4, 902),
+        ("text", "methods/semi_supervised_learning/textual_fpl.py", "methods.semi_supervised_learning", "TextualPrompt", "TextualFPL", 5, 14, 43, 4, 16, 901),
+        ("image", "methods/unsupervised_learning/visual_fpl.py", "methods.unsupervised_learning", "VisualPrompt", "VisualFPL", 5, 14, 47, 3, 16, 900),
     ],
 }
 ENCODER = {"small": "small", "vitb16": "ViT-B/16"}
@@ -121,7 +121,9 @@ ENCODER = {"small": "small", "vitb16": "ViT-B/16"}
 
 def label_ids(classes):
     """Global label ids that are neither contiguous nor in class order (the boards are keyed by them, :208-211)."""
-    return {c: 3 * ((5 * i + 2) % len(classes)) + 1 for i, c in enumerate(classes)}
+    ids = {c: 3 * ((7 * i + 2) % len(classes)) + 1 for i, c in enumerate(classes)}
+    assert len(set(ids.values())) == len(classes)
+    return ids
 
 
 def run_case(group, case, out):

@@ -19,7 +19,7 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 CLS = {"multi": ("MultimodalFPL", "trzsl"), "text": ("TextualFPL", "ssl"), "image": ("VisualFPL", "ul")}
-PROB_TOL = {"small": 2e-5, "vitb16": 4e-5}      # relative, fp32 GPU towers vs the CPU oracle's probabilities (measured: see the printed value)
+PROB_TOL = {"small": 5e-5, "vitb16": 5e-5}      # relative, fp32 GPU towers vs the CPU oracle's probabilities (measured: see the printed value)
 
 
 def _fixture(group):

@@ -1,0 +1,3 @@
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_split.py -x -q -m gpu -s > gpurun_out/t_split.log 2>&1
+grep -v "^$" gpurun_out/t_split.log | tail -n 40
