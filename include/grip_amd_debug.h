@@ -35,6 +35,9 @@ int grip_debug_ln_fold(const void* W, const float* gamma, const float* beta, con
 int grip_debug_gemm_split(int epi, const float* A, const float* W, int M, int N, int K, const float* bias, const float* resid, void* out,
                           void* a_split, void* w_split, int m_pad, void* stream);
 int grip_debug_split_rows(const float* x, void* out, int64_t rows, int K, void* stream);
+/* Attention of a precision-2 tower: qkv [B*S, 3*H*64] f32 -> out [B*S, H*64] in the split layout (4 bytes per element).  mfma != 0: the matrix-pipe
+ * kernel (csrc/attention_split.hip, S <= 320), else the f32 vector-ALU kernel writing the split layout (any S). */
+int grip_debug_attention_split(const void* qkv, void* out, int B, int S, int H, int causal, int mfma, void* stream);
 /* out[B*S, H*64] = softmax(q k^T / 8 [+ causal mask]) v for qkv[B*S, 3*H*64] (f16). */
 int grip_debug_attention(const void* qkv, void* out, int B, int S, int H, int causal, void* stream);
 /* The same in f32 (exact mode, csrc/attention_f32.hip): qkv and out f32, any S. */

@@ -236,6 +236,9 @@ int launch_attention_row_bwd(const half_t* qkv, const half_t* o_rows, const half
                              hipStream_t s);
 // split_out != 0: `out` is written in the split layout of gemm_split.hip (it feeds the out-proj GEMM of a precision-2 tower)
 int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s, int split_out = 0);
+// precision-2 towers, S <= 320 (attention_split.hip): f32 qkv in, both products as three f16 MFMAs on hi / lo' operand pairs, split-layout out
+bool attention_split_supported(int S);
+int launch_attention_fwd_split(const float* qkv, void* out, int B, int S, int H, int causal, hipStream_t s);
 // shared_rows > 0: shared-prefix layout; kv_part [B, shared_rows, 2, H*64] f32 scratch for the per-sequence dK / dV of the shared keys
 int launch_attention_bwd(const half_t* qkv, const half_t* o, const half_t* d_out, half_t* dqkv, int B, int S, int H, int causal, hipStream_t s,
                          int shared_rows = 0, float* kv_part = nullptr);

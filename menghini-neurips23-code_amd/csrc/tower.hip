@@ -487,7 +487,8 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, gf, w.M, d, s));
             a.f32 = gf; a.A = w.xn; a.W = t->wop(t->split ? lw.in_wS : lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_BIAS_F16, a, s));
-            if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s, t->split));
+            if (t->split && attention_split_supported(w.S)) RUN(launch_attention_fwd_split((const float*)(const void*)qkv, att, w.batch, w.S, H, causal, s));
+            else if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s, t->split));
             else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s, w.Ps));
         } else {
             a.A = x; a.W = t->w16 + lw.in_wG; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_bb; a.colsum = F + lw.in_cs; a.rowstat = w.rowstat;
@@ -660,6 +661,12 @@ extern "C" int grip_debug_gemm_split(int epi, const float* A, const float* W, in
 // f32 rows -> the split layout (out: 4 bytes per element), e.g. to read a split-layout result back on the host side of a test
 extern "C" int grip_debug_split_rows(const float* x, void* out, int64_t rows, int K, void* stream) {
     return launch_split_rows(x, out, rows, K, K, (hipStream_t)stream);
+}
+// Attention of a precision-2 tower: qkv f32 -> out in the split layout (4 bytes per element); mfma != 0: attention_split.hip (S <= 320), else the
+// f32 vector-ALU kernel with split output
+extern "C" int grip_debug_attention_split(const void* qkv, void* out, int B, int S, int H, int causal, int mfma, void* stream) {
+    if (mfma) return launch_attention_fwd_split((const float*)qkv, out, B, S, H, causal, (hipStream_t)stream);
+    return launch_attention_fwd_f32((const float*)qkv, (float*)out, B, S, H, causal, (hipStream_t)stream, 1);
 }
 extern "C" int grip_debug_attention_exact(const void* qkv, void* out, int B, int S, int H, int causal, void* stream) {
     return launch_attention_fwd_f32((const float*)qkv, (float*)out, B, S, H, causal, (hipStream_t)stream);

@@ -96,6 +96,7 @@ _DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of
     "grip_debug_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "grip_debug_gemm_split": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "grip_debug_split_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "grip_debug_attention_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

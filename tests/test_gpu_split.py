@@ -176,3 +176,27 @@ def test_three_tier_identical_lists_equal_the_exact_mode():
     assert (list(got2[0]), list(got2[1])) == (list(want[0]), list(want[1]))
     assert st3["tiers"] == 3 and st3["eps_mid"] < st3["eps"] / 30
     assert st3["rows_exact"] - st3["calibration_rows"] < 0.5 * (st2["rows_exact"] - st2["calibration_rows"]), (st3, st2)
+
+
+@pytest.mark.parametrize("B,S,H,causal", [(3, 197, 12, 0), (2, 213, 12, 0), (2, 50, 12, 0), (5, 77, 8, 1), (4, 21, 8, 1), (1, 320, 4, 0), (2, 257, 16, 0), (3, 1, 2, 1)])
+def test_split_attention_against_float64(B, S, H, causal):
+    """attention_split.hip (both products as three f16 MFMAs on hi / lo' pairs, f32 softmax) against float64 attention on the same f32
+    projections, next to the f32 vector-ALU kernel writing the same layout; output read back from the split layout."""
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(S * 31 + H)
+    D = H * 64
+    qkv = torch.randn(B * S, 3 * D, device="cuda", generator=g)
+    qkv[:, :D] *= 2.0          # sharper softmax rows
+    q, k, v = (qkv[:, i * D:(i + 1) * D].double().reshape(B, S, H, 64).permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((S, S), float("-inf"), device="cuda", dtype=torch.float64).triu(1)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    errs = {}
+    for mfma in (1, 0):
+        out = torch.zeros(B * S * D, device="cuda")
+        native.check(lib.grip_debug_attention_split(_p(qkv), _p(out), B, S, H, causal, mfma, _stream()))
+        got = _unsplit(out, B * S, D)
+        errs[mfma] = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f"B={B} S={S} H={H} causal={causal}: max err / max |out|: split MFMA kernel {errs[1]:.2e}, f32 VALU kernel {errs[0]:.2e}")
+    assert errs[1] <= 2e-6 and errs[0] <= 2e-6
