@@ -26,7 +26,7 @@ template <int KVC, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_split_kernel(const float* __restrict__ qkv, half_t* __restrict__ out, int S, int H) {
     constexpr int SP = KVC * 32;
     constexpr float LOG2E = 1.4426950408889634f;
-    constexpr float INV = 1.0f / 2048.0f;
+    constexpr float INV = 1.0f / (float)GRIP_SPLIT_LO_SCALE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Kh = (half_t*)smem;           // [SP][64], 16-byte chunk index XOR (key & 7)
     half_t* Kl = Kh + SP * 64;

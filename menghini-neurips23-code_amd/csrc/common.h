@@ -113,14 +113,23 @@ __device__ __forceinline__ f32x4 load4(const half_t* p, int i) {
 __device__ __forceinline__ void store4(float* p, int i, f32x4 v) { ((f32x4*)p)[i] = v; }
 __device__ __forceinline__ void store4(half_t* p, int i, f32x4 v) { ((half4*)p)[i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}; }
 // Split layout of the precision-2 tier (gemm_split.hip): per row and 32 consecutive columns one 128-byte line [32 x hi | 32 x lo'],
-// hi = f16(x), lo' = f16((x - hi) * 2^11).  SplitRow tags an output row pointer of that layout for store4.
+// hi = f16(x), lo' = f16((x - hi) * GRIP_SPLIT_LO_SCALE).  SplitRow tags an output row pointer of that layout for store4.
+#ifndef GRIP_SPLIT_LO_SCALE
+#define GRIP_SPLIT_LO_SCALE 1       // lo' = f16((x - hi) * this): 1 = unscaled (single-accumulator kernels; needs unflushed f16 subnormals in the MFMA),
+#endif                              // 2048 = the two-accumulator forms (nothing subnormal where hi is normal)
 struct SplitRow { half_t* p; };
 __device__ __forceinline__ void split_f16x4(f32x4 v, half4& hi, half4& lo) {
+    // hi and lo must come from ONE value.  Left to itself (HIP compiles with fp-contract=fast) the compiler fuses the subtraction with the multiply
+    // that produced v (v_fma_mix: lo = f16(x r - h) from the exact product) while a second copy of hi comes from the f32-rounded product
+    // (v_cvt_pk_f16_f32): at an f16 rounding tie of fl32(x r) the two disagree by an f16 ulp and hi + lo is off by 2^-11 (seen in the GELU
+    // epilogue: 2 of 65 536 elements).  The empty asm makes v opaque, so nothing upstream can be folded into either use.
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const half_t h = (half_t)v[e];
+        float x = v[e];
+        asm volatile("" : "+v"(x));
+        const half_t h = (half_t)x;
         hi[e] = h;
-        lo[e] = (half_t)((v[e] - (float)h) * 2048.0f);
+        lo[e] = (half_t)((x - (float)h) * (float)GRIP_SPLIT_LO_SCALE);
     }
 }
 __device__ __forceinline__ void store4(SplitRow r, int i, f32x4 v) {       // columns 4 i .. 4 i + 3 of the row
@@ -194,7 +203,8 @@ int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);
 // split-f16 tier (gemm_split.hip; GemmArgs.f32 == 2): A and W in the split layout ([32 x hi | 32 x lo'] f16 per 32 consecutive k, row pitch
 // 4 K bytes), f32 bias / residual / output -- EPI_BIAS_GELU_F16 writes its output in the split layout (it feeds the next split GEMM)
 int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s);
-int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s);
+int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight = 0);   // weights carry gemm_split_weight_scale()
+float gemm_split_weight_scale();
 
 // Activation buffers are f16 (default) or f32 (exact mode): the row kernels take untyped pointers plus the flag.  f32 == 2 (split-f16
 // tier): inputs f32 as in exact mode; launch_layernorm_f16 writes its OUTPUT (a GEMM operand) in the split layout of gemm_split.hip.

@@ -27,14 +27,18 @@
 #define SPL_ROWB 128                                   // bytes per LDS row: 32 hi + 32 lo' halfs
 #define SPL_STAGE_B ((SPL_BM + SPL_BN) * SPL_ROWB)     // 48 KiB
 #define SPL_NST 3
-#define SPL_LO_SCALE 2048.0f
-#define SPL_LO_INV (1.0f / 2048.0f)
+#ifndef SPL_PIPE
+#define SPL_PIPE 1          // 1 = register-pipelined K loop (hi fragments of the next step prefetched), 0 = all 16 reads at the top of the step
+#endif
+#define SPL_LO_INV (1.0f / (float)GRIP_SPLIT_LO_SCALE)
 
-__device__ __forceinline__ float quick_gelu_exact_s(float x) { return x / (1.0f + expf(-1.702f * x)); }
+// QuickGELU x * sigmoid(1.702 x) on v_exp_f32 + v_rcp_f32 (1 ulp each: far inside this tier's 2^-22; the f32 tower keeps IEEE exp and division)
+__device__ __forceinline__ float quick_gelu_exact_s(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x)); }
 
 // (hi / lo' of a value: split_f16x4 / store4(SplitRow, ...) in common.h -- the LayerNorm, the f32 attention and the GELU epilogue below
 // all write the layout through it)
 
+#if GRIP_SPLIT_LO_SCALE != 1
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -89,39 +93,115 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g, int tile
         }
 
     const int nk = g.K / 32;
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
+    // K rotation per column panel (as in gemm.hip): the column tiles of one row panel run side by side on an XCD and would all ask for the same
+    // slice of their shared A panel at the same moment; tile (., tn) walks its slices cyclically from slice tn * nk / tiles_n, so a slice is
+    // fetched by one tile and found in the L2 by the others.  The start depends on the column panel only: a row's result does not depend on the launch.
+    int ks = (int)(((int64_t)tn * nk) / tiles_n);
+    auto next_slice = [&](int k) { return k + 1 == nk ? 0 : k + 1; };
+    int ks_stage = ks;                      // slice the next DMA stage fetches
+    stage(0, ks_stage);
+    ks_stage = next_slice(ks_stage);
+    stage(1, ks_stage);                     // (nk == 1: the same slice again, into a slot nobody reads)
+    ks_stage = next_slice(ks_stage);
+#if SPL_PIPE
+    // Software pipeline over the K steps: the hi fragments of step kt + 1 are read from LDS while step kt multiplies, so a step starts on operands
+    // that are already in registers (two hi sets of 32 + one lo set of 32 fragment registers beside the 128 accumulators) and its 8 lo reads land
+    // under the 16 main products.  Costs DMA distance: stage kt + 1 must be visible at the top of step kt (one step of prefetch instead of two;
+    // with the K rotation most slices come out of the L2).  The loop is unrolled by two so the two hi sets swap roles without copies (K % 64 == 0);
+    // sched_barrier pins the intended order: all 16 reads, then the 48 MFMAs with one DMA piece of stage kt + 2 after every sixth.
+    half8 ah0[4], wh0[4], ah1[4], wh1[4];
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ah0[i] = *(const half8*)(lds + a_row + i * 16 * SPL_ROWB + swz_hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wh0[j] = *(const half8*)(lds + b_row + j * 16 * SPL_ROWB + swz_hi);
+    // (a use of the prologue's fragments in front of the loop: otherwise the loop head inherits "reads pending" from this path and every step
+    // would wait for all of its own 16 reads before its first product)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah0[i]), "v"(wh0[i]));
+    auto step = [&](int kt, half8 (&ah)[4], half8 (&wh)[4], half8 (&ahn)[4], half8 (&whn)[4]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of stage kt + 1 (issued one step ago)
+        __builtin_amdgcn_s_barrier();                             // stage kt + 1 visible; slot (kt + 2) % 3 fully read
+        const char* st = lds + (kt % SPL_NST) * SPL_STAGE_B;
+        const char* sn = lds + ((kt + 1) % SPL_NST) * SPL_STAGE_B;
+        half8 al[4], wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wl[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_lo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) al[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_lo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ahn[i] = *(const half8*)(sn + a_row + i * 16 * SPL_ROWB + swz_hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) whn[j] = *(const half8*)(sn + b_row + j * 16 * SPL_ROWB + swz_hi);
+        __builtin_amdgcn_sched_barrier(0);
+        char* abase = lds + ((kt + 2) % SPL_NST) * SPL_STAGE_B + wave * 32 * SPL_ROWB;
+        char* bbase = lds + ((kt + 2) % SPL_NST) * SPL_STAGE_B + SPL_BM * SPL_ROWB + wave * 16 * SPL_ROWB;
+        const char* as = a_src + (size_t)ks_stage * SPL_ROWB;
+        const char* ws = w_src + (size_t)ks_stage * SPL_ROWB;
+        ks_stage = next_slice(ks_stage);
+#pragma unroll
+        for (int q = 0; q < 48; ++q) {        // q = 0..15 main (j-major), 16..31 w_lo a_hi, 32..47 w_hi a_lo
+            const int i = q < 32 ? (q & 3) : ((q >> 2) & 3), j = q < 32 ? ((q >> 2) & 3) : (q & 3);
+            if (q < 16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+            else if (q < 32) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], cor[i][j], 0, 0, 0);
+            else cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], cor[i][j], 0, 0, 0);
+            if (q % 6 == 5 && q < 36) {
+                const int pc = q / 6;
+                if (pc < 4) __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)pc * 8 * pitch + lane_off), (AS3 void*)(abase + pc * 8 * SPL_ROWB), 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)(pc - 4) * 8 * pitch + lane_off), (AS3 void*)(bbase + (pc - 4) * 8 * SPL_ROWB), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, ah0, wh0, ah1, wh1);
+        step(kt + 1, ah1, wh1, ah0, wh0);
+    }
+#else
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt must have landed before the barrier certifies it to the other waves; stage kt + 1 (6 pieces of this wave) may stay in flight
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // stage kt visible to every wave; slot (kt + 2) % 3 = slot (kt - 1) % 3 fully read
-        if (kt + 2 < nk) stage((kt + 2) % SPL_NST, kt + 2);
+        // ONE basic block per K step: stage kt has landed when at most the 6 pieces of stage kt + 1 are in flight; the barrier certifies it to the
+        // other waves and frees slot (kt + 2) % 3 = (kt - 1) % 3; the 16 fragment reads go out first, in the order the MFMAs need them, and the
+        // 6 DMA pieces of stage kt + 2 are issued BETWEEN the MFMAs (as a burst in front of them they cost both waves of a SIMD 6 x 60-185
+        // cycles of issue at the same time).  Unconditional: past the end a valid slice is re-staged into a slot nobody reads.
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         const char* st = lds + (kt % SPL_NST) * SPL_STAGE_B;
         half8 ah[4], al[4], wh[4], wl[4];
+        wh[0] = *(const half8*)(st + b_row + swz_hi);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_hi);
-            al[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_lo);
-        }
+        for (int i = 0; i < 4; ++i) ah[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_hi);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wh[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_hi);
-            wl[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_lo);
-        }
+        for (int j = 1; j < 4; ++j) wh[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_hi);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) wl[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_lo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) al[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_lo);
+        stage((kt + 2) % SPL_NST, ks_stage);
+        ks_stage = next_slice(ks_stage);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], cor[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], cor[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) cor[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], cor[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);       // the fragment reads
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    // 6 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    // one DMA piece
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
     }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (dead) stages must have landed before the workgroup gives its LDS back
 
     // epilogue: lane (frow, fgrp) holds columns col0 + j*16 + fgrp*4 .. +3 of row row0 + i*16 + frow
     constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID);
@@ -148,42 +228,189 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g, int tile
     }
 }
 
+#endif   // two-accumulator form
+
+#if GRIP_SPLIT_LO_SCALE == 1
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Single-accumulator form (the default): with the lo parts UNSCALED (lo = f16(x - hi); gfx950's f16 MFMA takes subnormal inputs unflushed,
+// tools/micro/mfma_denorm.hip) all three products have the same scale and add into ONE accumulator, so the kernel affords the 256 x 256 tile
+// of the f16 kernels (8 waves as 2 x 4, 128 x 64 per wave = 8 x 4 fragments, 128 accumulator registers): per K step of 32 a wave issues 24
+// fragment reads for 96 MFMAs and the workgroup stages 64 KiB for 768 MFMAs -- a third less LDS traffic and DMA feed per MFMA than the
+// 256 x 128 two-accumulator form, which measured 290 - 330 TFLOP/s f32-equivalent (0.39 of the f16 MFMA peak; an LDS / feed limit: pipelining
+// its fragment reads through registers changed nothing).  Weights are stored scaled by 2^8 (exact) so that the lo part of a typical |w| ~ 0.02
+// is a normal f16 (2^8 w ~ 5, lo ~ 2e-3); the epilogue multiplies the accumulator by 2^-8.  Activations are unscaled: a lo part below the
+// normal range carries an absolute error <= 3e-8, far inside 2^-22 of the O(1) activations it sits among.
+// Two 64-KiB LDS stages; the DMA of stage kt + 1 is issued between the MFMAs of stage kt; all 24 reads of a step go out at its top in the
+// order the products need them (the MFMAs trail the reads; the exposed latency is the first read's).
+#define SP1_BM 256
+#define SP1_BN 256
+#define SP1_STAGE_B ((SP1_BM + SP1_BN) * SPL_ROWB)     // 64 KiB
+#define SP1_W_SCALE 256.0f
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * SP1_BM, n0 = tn * SP1_BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // staging: wave w fills rows [w*32, +32) of the A tile and of the W tile (4 + 4 pieces of 8 rows x 128 B)
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const size_t pitch = (size_t)g.K * 4;
+    const char* a_src = (const char*)g.A + (size_t)(m0 + wave * 32) * pitch;
+    const char* w_src = (const char*)g.W + (size_t)(n0 + wave * 32) * pitch;
+    const uint32_t lane_off = (uint32_t)srow * (uint32_t)pitch + (uint32_t)(schunk * 16);
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int swz_hi = (fgrp ^ (lane & 7)) * 16, swz_lo = ((4 + fgrp) ^ (lane & 7)) * 16;
+    const int a_row = (wr * 128 + frow) * SPL_ROWB;
+    const int b_row = SP1_BM * SPL_ROWB + (wc * 64 + frow) * SPL_ROWB;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / 32;
+    int ks_stage = (int)(((int64_t)tn * nk) / tiles_n);       // K rotation per column panel (see the two-accumulator kernel / gemm.hip)
+    auto next_slice = [&](int k) { return k + 1 == nk ? 0 : k + 1; };
+    {
+        char* abase = lds + wave * 32 * SPL_ROWB;
+        char* bbase = lds + SP1_BM * SPL_ROWB + wave * 32 * SPL_ROWB;
+        const char* as = a_src + (size_t)ks_stage * SPL_ROWB;
+        const char* ws = w_src + (size_t)ks_stage * SPL_ROWB;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)pc * 8 * pitch + lane_off), (AS3 void*)(abase + pc * 8 * SPL_ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)pc * 8 * pitch + lane_off), (AS3 void*)(bbase + pc * 8 * SPL_ROWB), 16, 0, 0);
+        }
+        ks_stage = next_slice(ks_stage);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage kt
+        __builtin_amdgcn_s_barrier();                         // stage kt visible; the other slot fully read
+        const char* st = lds + (kt & 1) * SP1_STAGE_B;
+        half8 ah[8], al[8], wh[4], wl[4];
+        wh[0] = *(const half8*)(st + b_row + swz_hi);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ah[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_hi);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) wh[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wl[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_lo);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) al[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_lo);
+        __builtin_amdgcn_sched_barrier(0);
+        // stage kt + 1 into the other slot, one piece after every tenth MFMA (past the end: a valid slice into a slot nobody reads)
+        char* abase = lds + ((kt + 1) & 1) * SP1_STAGE_B + wave * 32 * SPL_ROWB;
+        char* bbase = lds + ((kt + 1) & 1) * SP1_STAGE_B + SP1_BM * SPL_ROWB + wave * 32 * SPL_ROWB;
+        const char* as = a_src + (size_t)ks_stage * SPL_ROWB;
+        const char* ws = w_src + (size_t)ks_stage * SPL_ROWB;
+        ks_stage = next_slice(ks_stage);
+#pragma unroll
+        for (int q = 0; q < 96; ++q) {        // three passes over the 32 fragment pairs (j-major): w_hi a_hi, w_lo a_hi, w_hi a_lo
+            const int pass = q >> 5, j = (q >> 3) & 3, i = q & 7;
+            if (pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+            else if (pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
+            if (q % 10 == 9 && q < 80) {
+                const int pc = q / 10;
+                if (pc < 4) __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)pc * 8 * pitch + lane_off), (AS3 void*)(abase + pc * 8 * SPL_ROWB), 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)(pc - 4) * 8 * pitch + lane_off), (AS3 void*)(bbase + (pc - 4) * 8 * SPL_ROWB), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (dead) stage must have landed before the workgroup gives its LDS back
+
+    constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID);
+    const int row0 = m0 + wr * 128 + frow, col0 = n0 + wc * 64 + fgrp * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HAS_BIAS) b = *(const f32x4*)(g.bias + col0 + j * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = row0 + i * 16;
+            if (row >= g.M) continue;
+            const int col = col0 + j * 16;
+            f32x4 v = acc[i][j] * (1.0f / SP1_W_SCALE) + b;
+            if constexpr (EPI == EPI_BIAS_RESID) v += *(const f32x4*)((const float*)g.resid + (size_t)row * g.ldc + col);
+            if constexpr (EPI == EPI_BIAS_GELU_F16) {
+                v = (f32x4){quick_gelu_exact_s(v[0]), quick_gelu_exact_s(v[1]), quick_gelu_exact_s(v[2]), quick_gelu_exact_s(v[3])};
+                store4(SplitRow{(half_t*)g.out + (size_t)row * 2 * g.ldc}, col >> 2, v);
+            } else {
+                *(f32x4*)((float*)g.out + (size_t)row * g.ldc + col) = v;
+            }
+        }
+    }
+}
+#endif
+
 // x [rows, K] f32 (row pitch ld_in floats) -> split layout [rows, K/32, 64] halfs (weights at grip_tower_finalize; activations whose
 // producer does not write the layout itself).  One thread per 4 consecutive k.
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, half_t* __restrict__ out, int64_t rows, int K, int64_t ld_in) {
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, half_t* __restrict__ out, int64_t rows, int K, int64_t ld_in, float scale) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int k4 = K >> 2;
     if (i >= rows * k4) return;
     const int64_t r = i / k4;
     const int c = (int)(i - r * k4) * 4;
-    const f32x4 v = *(const f32x4*)(x + r * ld_in + c);
+    const f32x4 v = *(const f32x4*)(x + r * ld_in + c) * scale;
     store4(SplitRow{out + r * 2 * (int64_t)K}, c >> 2, v);
 }
 
-int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s) {
+float gemm_split_weight_scale() {
+#if GRIP_SPLIT_LO_SCALE == 1
+    return SP1_W_SCALE;
+#else
+    return 1.0f;
+#endif
+}
+
+int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight) {
     GRIP_REQUIRE(K % 32 == 0 && rows > 0 && ld_in >= K && ld_in % 4 == 0, "split_rows: need K %% 32 == 0 (rows=%lld K=%d ld=%lld)", (long long)rows, K, (long long)ld_in);
     const int64_t n = rows * (K / 4);
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (half_t*)out, rows, K, ld_in);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (half_t*)out, rows, K, ld_in, is_weight ? gemm_split_weight_scale() : 1.0f);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
 
 int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s) {
-    GRIP_REQUIRE(a.N % SPL_BN == 0 && a.K % 32 == 0 && a.M > 0, "gemm_split: need N %% 128 == 0 and K %% 32 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    GRIP_REQUIRE(a.K % 64 == 0 && a.M > 0, "gemm_split: need K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
     GRIP_REQUIRE(a.ldc % 32 == 0, "gemm_split: ldc %% 32 != 0");
     GRIP_REQUIRE((int64_t)a.K * 4 * 8 < ((int64_t)1 << 31), "gemm_split: K too large for 32-bit lane offsets");
-    const int tiles_m = (a.M + SPL_BM - 1) / SPL_BM, tiles_n = a.N / SPL_BN;
-    GRIP_REQUIRE(a.m_pad >= (int64_t)tiles_m * SPL_BM, "gemm_split: A must be allocated up to the 256-row tile (M=%d m_pad=%lld)", a.M, (long long)a.m_pad);
+#if GRIP_SPLIT_LO_SCALE == 1
+    constexpr int BM = SP1_BM, BN = SP1_BN;
+    constexpr size_t lds = (size_t)2 * SP1_STAGE_B;
+#define GRIP_SPLIT_KERNEL gemm_split1_kernel
+#else
+    constexpr int BM = SPL_BM, BN = SPL_BN;
     constexpr size_t lds = (size_t)SPL_NST * SPL_STAGE_B;
+#define GRIP_SPLIT_KERNEL gemm_split_kernel
+#endif
+    GRIP_REQUIRE(a.N % BN == 0, "gemm_split: need N %% %d == 0 (N=%d)", BN, a.N);
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
+    GRIP_REQUIRE(a.m_pad >= (int64_t)tiles_m * BM, "gemm_split: A must be allocated up to the 256-row tile (M=%d m_pad=%lld)", a.M, (long long)a.m_pad);
     dim3 grid(tiles_m * tiles_n), block(512);
 #define GRIP_GEMM_CASE(E)                                                                                                   \
     case E: {                                                                                                               \
         static bool configured = false;                                                                                     \
         if (!configured) {                                                                                                  \
-            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_split_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)GRIP_SPLIT_KERNEL<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             configured = true;                                                                                              \
         }                                                                                                                   \
-        hipLaunchKernelGGL((gemm_split_kernel<E>), grid, block, lds, s, a, tiles_m, tiles_n);                               \
+        hipLaunchKernelGGL((GRIP_SPLIT_KERNEL<E>), grid, block, lds, s, a, tiles_m, tiles_n);                               \
     } break;
     switch (epi) {
         GRIP_GEMM_CASE(EPI_F32)
@@ -193,6 +420,7 @@ int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s) {
         default: GRIP_REQUIRE(false, "gemm_split: epilogue %d is not part of the split-f16 (inference) path", epi);
     }
 #undef GRIP_GEMM_CASE
+#undef GRIP_SPLIT_KERNEL
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -329,6 +329,7 @@ extern "C" int grip_tower_create(const grip_dims* dims, void* f16_blob, void* f3
         grip_tower* t = new grip_tower();
         t->D = *dims;
         if (dims->precision < 0 || dims->precision > 2) { delete t; GRIP_REQUIRE(false, "dims.precision must be 0 (f16), 1 (f32 exact) or 2 (split f16)"); }
+        if (dims->precision == 2 && dims->width % 256 != 0) { delete t; GRIP_REQUIRE(false, "precision 2 (split f16) needs width %% 256 == 0 (256 x 256 GEMM tiles); width = %d", dims->width); }
         t->f32 = dims->precision != 0;
         t->split = dims->precision == 2;
         int rc = build_layout(*dims, t->L);
@@ -366,10 +367,10 @@ extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
         }
     if (t->split)   // split-layout copies of the block weights (the f32 originals stay: patch embedding and the final projection use them)
         for (const LayerW& w : t->L.layer) {
-            if ((rc = launch_split_rows((const float*)t->wop(w.in_w), t->wop(w.in_wS), 3 * d, d, d, s))) return rc;
-            if ((rc = launch_split_rows((const float*)t->wop(w.out_w), t->wop(w.out_wS), d, d, d, s))) return rc;
-            if ((rc = launch_split_rows((const float*)t->wop(w.fc_w), t->wop(w.fc_wS), 4 * d, d, d, s))) return rc;
-            if ((rc = launch_split_rows((const float*)t->wop(w.proj_w), t->wop(w.proj_wS), d, 4 * d, 4 * d, s))) return rc;
+            if ((rc = launch_split_rows((const float*)t->wop(w.in_w), t->wop(w.in_wS), 3 * d, d, d, s, 1))) return rc;
+            if ((rc = launch_split_rows((const float*)t->wop(w.out_w), t->wop(w.out_wS), d, d, d, s, 1))) return rc;
+            if ((rc = launch_split_rows((const float*)t->wop(w.fc_w), t->wop(w.fc_wS), 4 * d, d, d, s, 1))) return rc;
+            if ((rc = launch_split_rows((const float*)t->wop(w.proj_w), t->wop(w.proj_wS), d, 4 * d, 4 * d, s, 1))) return rc;
         }
     if ((rc = launch_transpose(t->wop(t->L.proj), t->wop(t->L.projT), f, d, t->D.embed_dim, t->D.embed_dim, s))) return rc;
     t->finalized = true;
@@ -653,7 +654,7 @@ extern "C" int grip_debug_gemm_split(int epi, const float* A, const float* W, in
                                      void* a_split, void* w_split, int m_pad, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     RUN(launch_split_rows(A, a_split, m_pad, K, K, s));
-    RUN(launch_split_rows(W, w_split, N, K, K, s));
+    RUN(launch_split_rows(W, w_split, N, K, K, s, 1));
     GemmArgs a{};
     a.f32 = 2; a.A = a_split; a.W = w_split; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid; a.out = out; a.ldc = N;
     return launch_gemm(epi, a, s);

@@ -311,6 +311,8 @@ def mid_tower(clip_model, n_rows):
     want = os.environ.get("GRIP_SPLIT_TIER", "auto")
     if want == "0" or (want == "auto" and n_rows < SPLIT_TIER_MIN_ROWS) or not hasattr(clip_model, "split_twin"):
         return None
+    if clip_model.dims.vision_width % 256:      # the split GEMM's 256 x 256 tiles (grip_tower_create refuses other widths at precision 2)
+        return None
     twin = clip_model.split_twin()
     return None if twin is None else twin.visual.tower
 
