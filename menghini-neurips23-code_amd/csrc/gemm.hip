@@ -1882,6 +1882,8 @@ static int launch_ringw(int epi, const GemmArgs& a, dim3 grid, hipStream_t s) {
     constexpr int BMT = 32 * WMF;
     const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.N / BN;
     constexpr size_t lds = (size_t)NST * (BMT + BN) * BK * 2;
+    // the ring's prologue fills NST - 1 slots: the K walk (of one split) must be at least that long
+    GRIP_REQUIRE((a.K / BK) / (a.ksplit > 1 ? a.ksplit : 1) >= NST - 1, "gemm_ringw: K walk of %d tiles is shorter than the %d-slot ring's prologue", (a.K / BK) / (a.ksplit > 1 ? a.ksplit : 1), NST);
 #define GRIP_GEMM_CASE(E)                                                                                                   \
     case E: {                                                                                                               \
         static bool configured = false;                                                                                     \

@@ -539,6 +539,11 @@ static int check_ws(grip_tower* t, int batch, int P, int train, void* ws, size_t
 // forward used that workspace before) and hands out a fresh generation number; an inference one invalidates it.
 static void note_forward(grip_tower* t, void* workspace, int train, const Workspace& w, const int32_t* eot, int prefix_classes, uint64_t* generation) {
     if (train) {
+        // Consumed entries only serve a clearer error message ("already back-propagated"); workspaces that were freed since (pools dropped with a
+        // key change, graph pins released per GRIP iteration) would otherwise stay in the map for good, and a recycled address could hit a stale one.
+        if (t->pending.size() > 32)
+            for (auto it = t->pending.begin(); it != t->pending.end();)
+                it = (it->second.consumed && it->first != workspace) ? t->pending.erase(it) : std::next(it);
         grip_tower::TrainState& st = t->pending[workspace];
         st.w = w; st.eot = eot; st.prefix_classes = prefix_classes; st.generation = ++t->generation; st.consumed = false;
         if (generation) *generation = st.generation;

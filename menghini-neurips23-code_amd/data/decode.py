@@ -54,8 +54,11 @@ def default_processes():
     """Decode processes for GRIP_DECODE_PROCS=auto: 1.5 per usable CPU, at most 48; 0 (= the thread back end) below 4 CPUs.
     More workers than CPUs because a worker also waits (file reads, the job / reply pipes, the parent's copy of its region):
     measured on the MI355X box's 16-CPU quota, files -> embeddings with the encode running: 12 / 16 / 20 / 24 processes =
-    9.5k / 10.3k / 11.8k / 13.3k images/s (tools/files_bench.py)."""
+    9.5k / 10.3k / 11.8k / 13.3k images/s (tools/files_bench.py).  Under a multi-rank launcher ($LOCAL_WORLD_SIZE) the CPUs are divided among the ranks."""
     n = usable_cpus()
+    # every rank of a node sees the same affinity mask / cgroup quota: share it (an 8-rank launch on a 16-CPU quota would start 192 workers)
+    local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    n = max(1, n // local)
     return min(48, (3 * n + 1) // 2) if n >= 4 else 0
 
 

@@ -243,6 +243,10 @@ class TrainingStrategy:
         device: one host synchronisation per epoch instead of three per batch.  `GRAPH_STEPS: False` or gradient accumulation
         (ACCUMULATION_ITER > 1) take the eager per-batch path."""
         classes, ids, lut = self._class_space(only_seen)
+        if self.modality in ("text", "multi"):
+            # features() / predict() / trained_features() re-point model.classes at their own class list between epochs; the eager fallback of a
+            # graphed step (ragged last batch) reads it at call time, so it is re-set here every epoch, not only when the graph is (re)built
+            self.model.classes = classes
         accum = int(getattr(self.config, "ACCUMULATION_ITER", 1))
         if accum != 1 or not getattr(self.config, "GRAPH_STEPS", True):
             return self._train_epoch_eager(train_loader, classes, ids, lut, accum)

@@ -161,15 +161,15 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     dev = [0.0, 0.0]                # largest deviation seen of a level-0 / level-1 value from the better value that replaced it
     n_mid = n_exact = 0
 
-    def to_exact(idx):
+    def to_exact(idx, measure=True):
         nonlocal n_exact
         idx = np.asarray(idx, dtype=np.int64)
         if idx.size == 0:
             return
         p32, a32 = exact_rows(idx)
         for lv in (0, 1):
-            sel = level[idx] == lv
-            if sel.any():
+            sel = (level[idx] == lv) & np.isfinite(probs[idx]).all(axis=1)       # (a non-finite row says nothing about the tier's accuracy)
+            if measure and sel.any():
                 dev[lv] = max(dev[lv], _deviation(probs[idx[sel]], p32[sel], abs_eps))
         probs[idx] = p32
         pred[idx] = a32
@@ -182,6 +182,12 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         if idx.size == 0:
             return
         pm, am = mid_rows(idx)
+        bad = ~np.isfinite(pm).all(axis=1)
+        if bad.any():       # an overflow inside the cheaper tower (f16 range): those rows go straight to the exact tower
+            to_exact(idx[bad], measure=False)
+            idx, pm, am = idx[~bad], pm[~bad], am[~bad]
+            if idx.size == 0:
+                return
         # the middle tier's value is itself only known to eps[1]: a screen value within d of it is within d (1 + eps1) + eps1 of the truth
         d = _deviation(probs[idx], pm, abs_eps)
         dev[0] = max(dev[0], d * (1.0 + eps[1]) + eps[1])
@@ -217,6 +223,9 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     if mid_rows is not None:
         dev[1] = _deviation(pm_cal, probs[cal], abs_eps)
     stats["calibration_rows"] = int(cal.size)
+    broken = np.flatnonzero(~np.isfinite(probs).all(axis=1))       # rows the screen overflowed on (f16 range): exact at once, outside every bound
+    stats["nonfinite_screen_rows"] = int(broken.size)
+    to_exact(broken, measure=False)
     eps = [bound(0), bound(1)]
     per_round = []
     g = np.random.default_rng(1000003 * n + int(min(k, 1 << 30)))      # the audit's draw: a function of the problem only (identical on every rank)

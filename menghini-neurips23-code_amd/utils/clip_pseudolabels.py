@@ -62,7 +62,8 @@ def _pool_images(dataset, transform, device):
             sel = [paths[int(i)] for i in idx]
             if not native_pre:
                 return torch.stack([transform(Image.open(p).convert("RGB")) for p in sel])
-            return transform.finish_chunk(transform.decode_chunk(sel, workers=workers, processes=procs))
+            # a handful of rows (a refinement round, the audit): the thread back end -- a job round trip through two dozen decode processes costs more
+            return transform.finish_chunk(transform.decode_chunk(sel, workers=workers, processes=procs if len(sel) >= 256 else 0))
     return _Lazy()
 
 

@@ -92,7 +92,9 @@ def test_pool_encode_is_bitwise_independent_of_the_chunking():
     x = torch.randn(900, 3, 224, 224, device="cuda", generator=g)
     tower = m.visual.tower
     outs = []
-    for chunk in (900, 450, 700, 333):          # 700 -> a 200-image tail, 333 -> a 234-image tail
+    # 700 -> a 200-image tail, 333 -> a 234-image tail; 40 and 8: launches small enough for the loader-wave ring kernel (gemm_ringw: a launch of at
+    # most one workgroup per CU) and the 192-row form, on either side of their thresholds
+    for chunk in (900, 450, 700, 333, 40, 8):
         o = torch.empty(900, 512, device="cuda")
         with torch.no_grad():
             tower.encode_chunks(x, o, 0, 900, chunk, streams=1)

@@ -254,3 +254,28 @@ def test_bench_quotes_pmc_traffic_only_for_the_exact_instantiation(tmp_path, mon
     assert bench.pmc_entry(slot) == (2.5e9, 0.5)
     assert bench.pmc_entry(6 * 16 + 8) == (None, None)                  # the file holds <8, 1, true>, the run uses <8, 2, true>
     assert bench.pmc_entry(0 * 16 + 3) == (None, None)                  # the f32 GEMM is not in the file
+
+
+def test_grip_schedule_matches_the_reference_formula():
+    """TrainingStrategy._n_pseudoshots against the literal arithmetic of methods/semi_supervised_learning/pseudo_iterative.py:62-75 (first
+    iteration) and :113-125 (ALL_UNLABELED growth; identical in the ul / trzsl twins): pseudo-shots per class at GRIP iteration 1 .. num_iter."""
+    import math
+
+    import grip_amd  # noqa: F401
+    from grip_amd.methods.training_strategies import TrainingStrategy
+
+    def reference_schedule(n_unlabeled, step_quantile, n_unseen):
+        num_iter = int(100 / step_quantile)                                   # :63
+        num_samples = int(n_unlabeled / num_iter)                             # :64
+        n_per_class = int(num_samples / n_unseen)                             # :66
+        shots = [n_per_class if n_per_class * n_unseen <= n_unlabeled else math.floor(n_unlabeled / n_unseen)]      # :68-75
+        for niter in range(1, num_iter):                                      # the value set at the END of iteration niter is used by iteration niter + 1
+            n_per_class = int((niter + 1) * num_samples / n_unseen)           # :114
+            shots.append(n_per_class if n_per_class * n_unseen <= n_unlabeled else math.floor(n_unlabeled / n_unseen))   # :116-125
+        return num_iter, num_samples, shots
+
+    for n_unlabeled, q, c in [(3120, 10, 47), (50000, 10, 102), (1000, 10, 38), (999, 20, 10), (57, 10, 18), (10, 50, 3), (7, 10, 2), (31500, 10, 45),
+                              (8144, 25, 196), (123, 10, 100), (5000, 1, 7)]:
+        num_iter, num_samples, want = reference_schedule(n_unlabeled, q, c)
+        got = [TrainingStrategy._n_pseudoshots(None, niter, num_samples, n_unlabeled, c) for niter in range(1, num_iter + 1)]
+        assert got == want, (n_unlabeled, q, c, got, want)

@@ -297,3 +297,17 @@ def test_deviation_is_relative_to_the_smaller_value():
     from grip_amd import pseudolabels as pl
     assert abs(pl._deviation(np.float32([0.5]), np.float32([1.0]), 0.0) - 1.0) < 1e-6      # |1 - 0.5| / 0.5: the scan's interval is around the APPROXIMATE value
     assert abs(pl._deviation(np.float32([1.0]), np.float32([0.5]), 0.0) - 1.0) < 1e-6
+
+
+def test_non_finite_rows_of_a_cheaper_tier_go_straight_to_the_exact_tower():
+    """An f16 overflow inside a cheaper tower gives NaN / inf probabilities: such rows are re-encoded exactly at once and never enter a bound."""
+    from oracle import cbind
+    p32, a32, p16, a16, paths = _pool(3000, 9, 0.4, 1e-3, 99)
+    r = np.random.RandomState(2)
+    pmid = (p32.astype(np.float64) * (1.0 + np.clip(r.randn(*p32.shape), -4, 4) * 1e-5)).astype(np.float32)
+    p16[[5, 700, 2999]] = np.nan
+    p16[1234, 3] = np.inf
+    pmid[[5, 44]] = np.nan
+    want = cbind.leaderboard_ref(p32, a32, paths, list(range(9)), 6)
+    got, st = _refine3(p32, a32, pmid, p16, p16.argmax(1).astype(np.int32), paths, 6)
+    assert got == want and st["nonfinite_screen_rows"] in (3, 4) and np.isfinite(st["eps"]) and np.isfinite(st["eps_mid"]) and st["eps"] < 2e-2
