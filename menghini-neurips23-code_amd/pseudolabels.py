@@ -141,7 +141,8 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     sits at level 0 (screen), 1 (middle) or 2 (exact, final).  Level-0 / level-1 values are trusted only up to a relative bound
     eps[level] = safety x (largest deviation seen so far between a value of that level and the better value that later replaced it),
     plus an absolute slack `abs_eps` for values in the denormal range; the bounds start from `calib` rows -- at most 1/16 of the pool,
-    at least 16 -- spread evenly over it, which go through every tier.  grip_leaderboard_scan_bounded marks every non-final row
+    at least 16 -- spread evenly over it: all of them through the next tier up, every fourth through the exact tower as well when there
+    is a middle tier.  grip_leaderboard_scan_bounded marks every non-final row
     that takes part in a comparison its bound cannot decide; marked rows move up one tier and the scan repeats until nothing is
     marked and no bound has moved: the lists are then certified, decision by decision, to be those of the scan over the all-f32
     probabilities PROVIDED every non-final row obeys its bound.
@@ -217,12 +218,26 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than 16 (a bound from one or two rows is no bound)
     cal = np.unique(np.linspace(0, n - 1, min(n, max(16, min(calib, n // 16)))).astype(np.int64))
     if mid_rows is not None:
-        pm_cal, _ = mid_rows(cal)
-        n_mid += cal.size
-    to_exact(cal)
-    if mid_rows is not None:
-        dev[1] = _deviation(pm_cal, probs[cal], abs_eps)
+        # With a middle tier the screen's bound is calibrated against IT (every calibration row; its own error is folded in), and the middle
+        # tier's bound against the exact tower on every fourth calibration row (at least 16): its deviations are f32-rounding-sized and tightly
+        # distributed (three f16 products with f32 accumulation: ~3 x 2^-23 per term), the rows the scan sends on to the exact tower and the
+        # audit keep adding to the sample, and an f32 row costs 2.5x a split-f16 one.
+        cal_x = cal[:: max(1, len(cal) // max(16, len(cal) // 4))]
+        pm_x, _ = mid_rows(cal_x)
+        n_mid += cal_x.size
+        p32_x, a32_x = exact_rows(cal_x)
+        n_exact += cal_x.size
+        dev[1] = _deviation(pm_x, p32_x, abs_eps)
+        eps[1] = bound(1)
+        fin = np.isfinite(probs[cal_x]).all(axis=1)
+        if fin.any():
+            dev[0] = _deviation(probs[cal_x[fin]], p32_x[fin], abs_eps)
+        probs[cal_x], pred[cal_x], level[cal_x] = p32_x, a32_x, 2
+        to_mid(cal[level[cal] == 0])
+    else:
+        to_exact(cal)
     stats["calibration_rows"] = int(cal.size)
+    stats["calibration_rows_exact"] = int((level[cal] == 2).sum())
     broken = np.flatnonzero(~np.isfinite(probs).all(axis=1))       # rows the screen overflowed on (f16 range): exact at once, outside every bound
     stats["nonfinite_screen_rows"] = int(broken.size)
     to_exact(broken, measure=False)

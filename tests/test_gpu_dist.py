@@ -98,7 +98,8 @@ def test_bench_two_ranks(tmp_path):
     # the default mode carries the index guarantee on N ranks too (each rank re-encodes the marked rows of its own shard)
     assert d["config"]["pseudolabel_mode"] == "identical" and d["identical"]["rows_reencoded_exactly"] > 0 and d["identical_images_per_sec"] > 0
     st = d["stage_seconds_over_ranks"]
-    assert set(st) == {"encode_f16", "allgather", "head_scan", "refine_exact", "train"} and all(v["max_s"] >= v["min_s"] >= 0 for v in st.values())
+    assert set(st) == {"encode_f16", "allgather", "head_scan", "refine_split", "refine_exact", "train"} and all(v["max_s"] >= v["min_s"] >= 0 for v in st.values())
+    assert d["identical"]["tiers"] == 3 and d["identical"]["rows_reencoded_split_f16"] >= d["identical"]["rows_reencoded_exactly"]
     assert [r["rank"] for r in d["ranks_seen"]] == [0, 1]
 
 

@@ -311,3 +311,29 @@ def test_non_finite_rows_of_a_cheaper_tier_go_straight_to_the_exact_tower():
     want = cbind.leaderboard_ref(p32, a32, paths, list(range(9)), 6)
     got, st = _refine3(p32, a32, pmid, p16, p16.argmax(1).astype(np.int32), paths, 6)
     assert got == want and st["nonfinite_screen_rows"] in (3, 4) and np.isfinite(st["eps"]) and np.isfinite(st["eps_mid"]) and st["eps"] < 2e-2
+
+
+@pytest.mark.parametrize("dominant,k", [(True, 16), (False, 5), (True, 10000000)])
+def test_parallel_prefilter_changes_nothing(monkeypatch, dominant, k):
+    """The bounded scan with its worker-thread pre-filter (large pools: the replicated scan of a multi-GPU pass walks N_total x C) marks the same
+    rows and returns the same lists as the single-threaded scan, round after round, and the refined lists equal the plain-C oracle's."""
+    import grip_amd  # noqa: F401
+    from grip_amd import engine, pseudolabels as pl
+    from oracle import cbind
+    n, c = 70000, 64
+    p32, a32, p16, a16, paths = _pool(n, c, 0.25, 2e-3, 4242, dominant=dominant)
+    ranks = pl.path_ranks(paths)
+    rel = np.full(n, 1.5e-2, np.float32)
+    rel[::7] = 0
+    out = {}
+    for threads in ("1", "6"):
+        monkeypatch.setenv("GRIP_SCAN_THREADS", threads)
+        out[threads] = engine.leaderboard_scan_bounded(p16, a16, ranks, rel, k, 1e-30)
+    for a, b in zip(out["1"], out["6"]):
+        assert np.array_equal(a, b)
+    assert out["1"][2].any() or k == pl.K_ALL
+    monkeypatch.setenv("GRIP_SCAN_THREADS", "6")
+    if k != pl.K_ALL:
+        want = cbind.leaderboard_ref(p32, a32, paths, list(range(c)), k)
+        got, st = _refine(p32, a32, p16, a16, paths, k)
+        assert got == want
