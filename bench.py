@@ -852,6 +852,12 @@ def main():
             out["secondary"] = secondary_block(loop, lib)
             if structured is not None:
                 out["secondary"]["identical_on_structured_pool"] = structured
+                # the headline pool is degenerate (i.i.d. noise through random-init towers: one class wins nearly every arg-max); the same pass on a
+                # pool WITH class structure re-encodes more rows -- quoted beside the headline, not instead of it (BASELINE.json names synthetic data)
+                out["config"]["structured_pool_identical_pass_images_per_sec"] = structured.get("identical_images_per_sec")
+                out["config"]["headline_pool_note"] = ("i.i.d. N(0,1) images (SURVEY 8d): a random-init tower gives nearly every image the same arg-max; "
+                                                       "`structured_pool_identical_pass_images_per_sec` is the pseudolabel pass (no prompt steps) on a class-structured pool, "
+                                                       "to be compared with `identical_images_per_sec`")
             try:
                 out["secondary"]["from_files"] = from_files_block(loop)
             except Exception as e:      # the input pipeline is a NEXT row: its failure must not take the bench line down

@@ -14,7 +14,8 @@
  *
  * Dtypes: GEMM operands and the residual stream f16 (MFMA v_mfma_f32_16x16x32_f16, f32 accumulate, adds into the
  * stream in f32); LayerNorm statistics, softmax, head, embeddings and gradients f32.  A tower created with
- * dims.precision = 1 computes everything in f32 instead (exact comparison mode, inference only).
+ * dims.precision = 1 computes everything in f32 instead (exact comparison mode, inference only); dims.precision = 2 is the f32 tower with its
+ * block GEMMs and attention on the f16 matrix pipes as hi / lo operand pairs (three products, f32 accumulate: ~22 mantissa bits; inference only).
  */
 #ifndef GRIP_AMD_H
 #define GRIP_AMD_H
@@ -58,7 +59,13 @@ typedef struct {
     int32_t precision;   /* 0 = f16 GEMM operands + f16 residual stream (what clip.load gives the reference on a GPU);
                             1 = exact comparison mode: f32 weights, activations, residual stream and attention
                             (v_mfma_f32_16x16x4_f32), i.e. the arithmetic of the reference's CPU path (clip.load(..., "cpu")
-                            keeps fp32).  Inference only: train != 0 is GRIP_ERR_ARG on a precision-1 tower. */
+                            keeps fp32).  Inference only: train != 0 is GRIP_ERR_ARG on a precision-1 tower.
+                            2 = split f16 (the middle tier of the screen-and-refine pseudolabel pass): blobs, activations, residual stream,
+                            LayerNorm, softmax and every interface as precision 1; the four GEMMs of a block and the attention products
+                            carry each operand as f16 hi + f16 lo (x = hi + lo) and form a b from three v_mfma_f32_16x16x32_f16 with f32
+                            accumulation (a_hi b_hi + a_hi b_lo + a_lo b_hi): embeddings within ~1e-6 relative of the precision-1 tower's
+                            at ~2.5x its throughput.  grip_tower_finalize derives the split weight copies (slots "...#S").  Inference
+                            only; width must be a multiple of 256. */
 } grip_dims;
 
 /* Weight layout.  A tower's frozen weights live in two caller-owned device blobs: one f16 (GEMM
@@ -69,7 +76,7 @@ typedef struct {
  * written by grip_tower_finalize).  Returns GRIP_OK, or GRIP_ERR_ARG when `slot` is past the end. */
 typedef struct {
     char name[96];
-    int32_t dtype;      /* 0 = GEMM-operand blob (f16; f32 elements when dims.precision = 1), 1 = f32 blob */
+    int32_t dtype;      /* 0 = GEMM-operand blob (f16; f32 elements when dims.precision != 0), 1 = f32 blob */
     int32_t derived;    /* 1 = written by grip_tower_finalize */
     int64_t offset;     /* element offset inside its blob (16-byte aligned) */
     int64_t rows;       /* logical shape rows x cols, row-major */
@@ -83,7 +90,7 @@ int grip_layout_size(const grip_dims* dims, int64_t* n_f16, int64_t* n_f32);
 typedef struct grip_tower grip_tower;
 
 /* Replaces clip.load's module construction for one tower.  Blobs must outlive the handle.  `f16_blob` is the GEMM-operand
- * blob of n_f16 ELEMENTS: f16, or f32 when dims.precision = 1. */
+ * blob of n_f16 ELEMENTS: f16, or f32 when dims.precision != 0. */
 int grip_tower_create(const grip_dims* dims, void* f16_blob, void* f32_blob, grip_tower** out);
 /* Builds derived weights (transposed copies) on `stream`; call after the primary slots are filled
  * and again whenever they change. */
@@ -133,7 +140,7 @@ int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* 
  *              instead of n_class * seq_len: 425 instead of 2 142 for 102 classes x 21 positions, 16 context tokens); the
  *              class positions attend to the shared keys and their own, and the backward adds every class's share of
  *              the shared keys' gradient in class order.  Embeddings and prompt gradient are the same function of the
- *              inputs; ignored (plain layout) when prefix_classes != 1, n_prefix == 0 or dims.precision == 1.
+ *              inputs; ignored (plain layout) when prefix_classes != 1, n_prefix == 0 or dims.precision != 0.
  */
 #define GRIP_FWD_TRAIN 1
 #define GRIP_FWD_SHARED_PREFIX 2
