@@ -22,8 +22,8 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8& hi, 
     lo = (half8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 }
 
-template <int KVC, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_split_kernel(const float* __restrict__ qkv, half_t* __restrict__ out, int S, int H) {
+template <int KVC, bool CAUSAL, int NW>       // NW waves per workgroup: 8 from 97 tokens on (two waves per SIMD: staging and the 13 - 20 query tiles in two or three rounds), else 4
+__global__ __launch_bounds__(NW * 64) void attn_fwd_split_kernel(const float* __restrict__ qkv, half_t* __restrict__ out, int S, int H) {
     constexpr int SP = KVC * 32;
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr float INV = 1.0f / (float)GRIP_SPLIT_LO_SCALE;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split_kernel(const float* __rest
     const int li = lane & 15, lg = lane >> 4;
     const int n_qt = (S + 15) >> 4;
 
-    for (int idx = tid; idx < SP * 8; idx += 256) {
+    for (int idx = tid; idx < SP * 8; idx += NW * 64) {
         const int row = idx >> 3, chunk = idx & 7;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
         if (row < S) {
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split_kernel(const float* __rest
         *(half8*)(Kl + o) = lo;
     }
     // V image: a lane takes a PAIR of keys (2r, 2r+1) and one 8-wide slice of the head dim and writes eight 32-bit words {V[2r][d], V[2r+1][d]} per plane
-    for (int idx = tid; idx < ((SP / 2 + 31) / 32) * 256; idx += 256) {
+    for (int idx = tid; idx < ((SP / 2 + 31) / 32) * 256; idx += NW * 64) {
         const int lane_rp = idx & 31, chunk = ((idx >> 5) & 1) + 2 * ((idx >> 6) & 3), rblk = idx >> 8;
         const int r0 = 2 * (rblk * 32 + lane_rp);
         if (r0 >= SP) continue;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_fwd_split_kernel(const float* __rest
     }
     __syncthreads();
 
-    for (int qt = wave; qt < n_qt; qt += 4) {
+    for (int qt = wave; qt < n_qt; qt += NW) {
         asm volatile("" ::: "memory");   // keep the fragment reads inside the tile loop
         const int qrow = qt * 16 + li;
         const int qr = qrow < S ? qrow : S - 1;
@@ -166,12 +166,12 @@ int launch_attention_fwd_split(const float* qkv, void* out, int B, int S, int H,
     case K: {                                                                                                                                \
         static bool configured = false;                                                                                                      \
         if (!configured) {                                                                                                                   \
-            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_split_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_split_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_split_kernel<K, false, (K >= 4 ? 8 : 4)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_split_kernel<K, true, (K >= 4 ? 8 : 4)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
             configured = true;                                                                                                               \
         }                                                                                                                                    \
-        if (causal) hipLaunchKernelGGL((attn_fwd_split_kernel<K, true>), dim3(B * H), dim3(256), lds, s, qkv, (half_t*)out, S, H);           \
-        else hipLaunchKernelGGL((attn_fwd_split_kernel<K, false>), dim3(B * H), dim3(256), lds, s, qkv, (half_t*)out, S, H);                 \
+        if (causal) hipLaunchKernelGGL((attn_fwd_split_kernel<K, true, (K >= 4 ? 8 : 4)>), dim3(B * H), dim3((K >= 4 ? 8 : 4) * 64), lds, s, qkv, (half_t*)out, S, H); \
+        else hipLaunchKernelGGL((attn_fwd_split_kernel<K, false, (K >= 4 ? 8 : 4)>), dim3(B * H), dim3((K >= 4 ? 8 : 4) * 64), lds, s, qkv, (half_t*)out, S, H);       \
     } break;
     switch (kvc) {
         GRIP_ATT_CASE(1) GRIP_ATT_CASE(2) GRIP_ATT_CASE(3) GRIP_ATT_CASE(4) GRIP_ATT_CASE(5)

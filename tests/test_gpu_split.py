@@ -210,3 +210,20 @@ def test_split_attention_against_float64(B, S, H, causal):
         errs[mfma] = ((got - ref).abs().max() / ref.abs().max()).item()
     print(f"B={B} S={S} H={H} causal={causal}: max err / max |out|: split MFMA kernel {errs[1]:.2e}, f32 VALU kernel {errs[0]:.2e}")
     assert errs[1] <= 2e-6 and errs[0] <= 2e-6
+
+
+def test_long_sequences_keep_the_f32_attention_with_split_output():
+    """S = 577 (ViT-L/14@336px) is beyond attention_split.hip's four LDS planes: a precision-2 tower then runs the f32 vector-ALU attention and
+    only its OUTPUT is written in the split layout (csrc/tower.hip run_blocks)."""
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, S, H = 1, 577, 16
+    D = H * 64
+    qkv = torch.randn(B * S, 3 * D, device="cuda", generator=g)
+    q, k, v = (qkv[:, i * D:(i + 1) * D].double().reshape(B, S, H, 64).permute(0, 2, 1, 3) for i in range(3))
+    ref = ((q @ k.transpose(-1, -2) / 8.0).softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * S, D)
+    out = torch.zeros(B * S * D, device="cuda")
+    native.check(lib.grip_debug_attention_split(_p(qkv), _p(out), B, S, H, 0, 0, _stream()))
+    assert ((_unsplit(out, B * S, D) - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+    with pytest.raises(native.GripError):
+        native.check(lib.grip_debug_attention_split(_p(qkv), _p(out), B, S, H, 0, 1, _stream()))
