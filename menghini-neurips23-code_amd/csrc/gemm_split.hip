@@ -230,6 +230,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g, int tile
 
 #endif   // two-accumulator form
 
+// (r04 experiment, removed: the LDS-DMA pieces as inline asm.  Through the builtin the compiler's wait-count pass turns EVERY lgkmcnt wait of a kernel
+// that contains an LDS-DMA instruction into lgkmcnt(0) -- the first MFMA of a K step then waits for all the fragment reads issued before it; with the
+// pieces hidden in asm the same reads get lgkmcnt(4), (7), (10) ...  Correct, and not faster: 354 / 336 TF/s either way.  Like every restructuring of
+// the f16 kernels, it lands on the ~1.05 PF/s of MFMA rate this power envelope gives a kernel that also feeds itself.)
+
 #if GRIP_SPLIT_LO_SCALE == 1
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // Single-accumulator form (the default): with the lo parts UNSCALED (lo = f16(x - hi); gfx950's f16 MFMA takes subnormal inputs unflushed,
@@ -301,17 +306,16 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
         __builtin_amdgcn_s_barrier();                         // stage kt visible; the other slot fully read
         const char* st = lds + (kt & 1) * SP1_STAGE_B;
         half8 ah[8], al[8], wh[4], wl[4];
+        // The hi fragments (12 reads) go out first; the 12 lo reads follow BETWEEN the first 24 MFMAs, which only need hi operands.  (All 24 up
+        // front would exceed the 4-bit lgkmcnt: the compiler then waits for every read before the first product -- 192 ds_read_b128 per
+        // workgroup and K step in front of idle matrix pipes.)
         wh[0] = *(const half8*)(st + b_row + swz_hi);
 #pragma unroll
         for (int i = 0; i < 8; ++i) ah[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_hi);
 #pragma unroll
         for (int j = 1; j < 4; ++j) wh[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_hi);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wl[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_lo);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) al[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_lo);
         __builtin_amdgcn_sched_barrier(0);
-        // stage kt + 1 into the other slot, one piece after every tenth MFMA (past the end: a valid slice into a slot nobody reads)
+        // stage kt + 1 into the other slot, one piece after every twelfth MFMA (past the end: a valid slice into a slot nobody reads)
         char* abase = lds + ((kt + 1) & 1) * SP1_STAGE_B + wave * 32 * SPL_ROWB;
         char* bbase = lds + ((kt + 1) & 1) * SP1_STAGE_B + SP1_BM * SPL_ROWB + wave * 32 * SPL_ROWB;
         const char* as = a_src + (size_t)ks_stage * SPL_ROWB;
@@ -323,8 +327,14 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
             if (pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
             else if (pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
-            if (q % 10 == 9 && q < 80) {
-                const int pc = q / 10;
+            if (q < 24 && !(q & 1)) {         // a lo read after every other MFMA of the first 24: w_lo 0..3, then a_lo 0..7
+                const int r = q >> 1;
+                if (r < 4) wl[r] = *(const half8*)(st + b_row + r * 16 * SPL_ROWB + swz_lo);
+                else al[r - 4] = *(const half8*)(st + a_row + (r - 4) * 16 * SPL_ROWB + swz_lo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q % 12 == 11) {
+                const int pc = q / 12;
                 if (pc < 4) __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)pc * 8 * pitch + lane_off), (AS3 void*)(abase + pc * 8 * SPL_ROWB), 16, 0, 0);
                 else __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)(pc - 4) * 8 * pitch + lane_off), (AS3 void*)(bbase + (pc - 4) * 8 * SPL_ROWB), 16, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
