@@ -180,8 +180,8 @@ int grip_weighted_ce(const float* logits, const int32_t* labels, const float* ro
  * UPTModel's prompt mixer (models/prompts_models.py:99-119 construct it, :129-146 run it): proj_coop_pre / proj_vpt_pre (Linear
  * to `dim`), clip.model.Transformer(width = dim, layers = 1, heads = 1) over the sequence cat((coop, vpt), dim 0) = [2, P, dim]
  * (sequence length 2, batch P), the .to(float16) round trip of :138-145, proj_coop_post / proj_vpt_post.  The only trainable
- * weights on the path: grip_upt_mixer_backward returns the gradient of EVERY tensor of the struct (float32 parameters; the
- * reference's float16 branch, multimodal_prompt.py:46, stays on the host framework's kernels).
+ * weights on the path: grip_upt_mixer_backward returns the gradient of EVERY tensor of the struct (float32 values; the
+ * reference's float16 branch, multimodal_prompt.py:46, is the same kernels with fp16 rounding points: half_linears).
  * One struct describes the tensors (forward: values; backward's `grads`: buffers of the same shapes that receive the gradients):
  *   coop [P, text_width], vpt [P, vision_width]                 coop_embeddings / vpt_embeddings (P = n_prompt tokens each)
  *   coop_pre_w [dim, text_width], coop_pre_b [dim]              proj_coop_pre;   vpt_pre_* likewise with vision_width
@@ -194,6 +194,11 @@ int grip_weighted_ce(const float* logits, const int32_t* labels, const float* ro
  * autograd does.  All device pointers f32; work is enqueued on `stream`; no atomics (bit-reproducible). */
 typedef struct {
     int32_t n_prompt, text_width, vision_width, dim;
+    int32_t half_linears;   /* 1 = the reference's float16 branch (multimodal_prompt.py:46 on a GPU): the four projection Linears and the two prompt embeddings are
+                               fp16 tensors around the fp32 block.  The host passes their values as f32 (exactly representable); the outputs of the pre / post
+                               projections are rounded to fp16, and in the backward so are the gradient entering proj_*_pre (it crosses the fp16 -> fp32 cast
+                               in front of the block) and the prompt gradients.  Parameter gradients come back f32; the host casts them to the parameters' dtype. */
+    int32_t reserved_;
     float *coop, *vpt;
     float *coop_pre_w, *coop_pre_b, *vpt_pre_w, *vpt_pre_b;
     float *ln1_g, *ln1_b, *in_w, *in_b, *out_w, *out_b, *ln2_g, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b;

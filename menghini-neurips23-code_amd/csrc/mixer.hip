@@ -25,7 +25,7 @@ struct MixDesc {          // Y[R, N] = epi(pro(X)[R, K] * W[N, K]^T + bias)
     float *save0, *save1;               // prologue results written once (workgroup 0)
     const float* e0; float* e1;         // epilogue operands
 };
-struct MixLaunch { MixDesc d[2]; int n; int pro, epi; };
+struct MixLaunch { MixDesc d[2]; int n; int pro, epi; int round_pro; };      // round_pro: PRO_LNBWD_ADD rounds its result to fp16 (see half_linears)
 
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void mixer_linear_kernel(MixLaunch L) {
             c1 = wave_sum(c1) / (float)K; c2 = wave_sum(c2) / (float)K;
             for (int k = lane; k < K; k += 64) {
                 const float g = dz[k] * D.p1[k], xh = (x[k] - mean) * rstd;
-                const float dx = D.p3[r * K + k] + rstd * (g - c1 - xh * c2);
+                float dx = D.p3[r * K + k] + rstd * (g - c1 - xh * c2);
+                if (L.round_pro) dx = (float)(half_t)dx;       // the gradient crosses the fp16 -> fp32 cast in front of the block (autograd casts it back)
                 Xs[r * K + k] = dx;
                 if (writer && D.save0) D.save0[r * K + k] = dx;
             }
@@ -286,7 +287,8 @@ extern "C" int grip_upt_mixer_forward(const grip_upt_mixer* m, float* coop_out, 
         hipStream_t s = (hipStream_t)stream;
         MixLaunch L{};
         // x0 = [proj_coop_pre(coop); proj_vpt_pre(vpt)]   (prompts_models.py:130-135; the cat along dim 0 makes the sequence axis)
-        L.n = 2; L.pro = PRO_NONE; L.epi = MEPI_NONE;
+        const int hl = m->half_linears != 0;       // fp16 Linears (multimodal_prompt.py:46): their outputs are fp16 tensors
+        L.n = 2; L.pro = PRO_NONE; L.epi = hl ? MEPI_F16ROUND : MEPI_NONE;
         L.d[0] = MixDesc{m->coop, dt, m->coop_pre_w, dt, m->coop_pre_b, w.x0, D, P, D, dt, P};
         L.d[1] = MixDesc{m->vpt, dv, m->vpt_pre_w, dv, m->vpt_pre_b, w.x0 + (size_t)P * D, D, P, D, dv, P};
         RUNM(launch_linear(L, s));
@@ -307,7 +309,7 @@ extern "C" int grip_upt_mixer_forward(const grip_upt_mixer* m, float* coop_out, 
         L.d[0] = MixDesc{w.g, 4 * D, m->proj_w, 4 * D, m->proj_b, w.x2, D, R, D, 4 * D, P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, w.x1, w.out16};
         RUNM(launch_linear(L, s));
         // coop_embs = proj_coop_post(out16[0]); vpt_embs = proj_vpt_post(out16[1])
-        L = MixLaunch{}; L.n = 2; L.pro = PRO_NONE; L.epi = MEPI_NONE;
+        L = MixLaunch{}; L.n = 2; L.pro = PRO_NONE; L.epi = hl ? MEPI_F16ROUND : MEPI_NONE;
         L.d[0] = MixDesc{w.out16, D, m->coop_post_w, D, m->coop_post_b, coop_out, dt, P, dt, D, P};
         L.d[1] = MixDesc{w.out16 + (size_t)P * D, D, m->vpt_post_w, D, m->vpt_post_b, vpt_out, dv, P, dv, D, P};
         RUNM(launch_linear(L, s));
@@ -362,7 +364,8 @@ extern "C" int grip_upt_mixer_backward(const grip_upt_mixer* m, const float* d_c
         L.d[0] = MixDesc{w.d_o, D, w.T_in, 3 * D, nullptr, w.dy, D, R, D, 3 * D, P, w.qkv, nullptr, nullptr, nullptr, w.dqkv, nullptr};
         RUNM(launch_linear(L, s));
         // d_x0 = d_x1 + LN1'(dy);  d coop = d_x0[0] W_cp, d vpt = d_x0[1] W_vp   (both problems recompute d_x0's P rows of their half)
-        L = MixLaunch{}; L.n = 2; L.pro = PRO_LNBWD_ADD; L.epi = MEPI_NONE;
+        // (fp16 Linears: d_x0 is rounded to fp16 where it crosses the cast in front of the block, and so are the prompt gradients the fp16 Linears return)
+        L = MixLaunch{}; L.n = 2; L.pro = PRO_LNBWD_ADD; L.epi = m->half_linears ? MEPI_F16ROUND : MEPI_NONE; L.round_pro = m->half_linears != 0;
         L.d[0] = MixDesc{w.dy, D, w.T_cp, D, nullptr, g->coop, dt, P, dt, D, P, w.x0, m->ln1_g, w.st1, w.d_x1, w.d_x0, nullptr};
         L.d[1] = MixDesc{w.dy + (size_t)P * D, D, w.T_vp, D, nullptr, g->vpt, dv, P, dv, D, P, w.x0 + (size_t)P * D, m->ln1_g, w.st1 + 2 * P, w.d_x1 + (size_t)P * D,
                          w.d_x0 + (size_t)P * D, nullptr};

@@ -466,10 +466,12 @@ class UptMixerFn(torch.autograd.Function):
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         coop_out = torch.empty(P, dt, dtype=torch.float32, device=dev)
         vpt_out = torch.empty(P, dv, dtype=torch.float32, device=dev)
-        m = native.UptMixer(P, dt, dv, D, *[t.data_ptr() for t in ts])
+        # the reference's float16 branch (multimodal_prompt.py:46): fp16 projection Linears / prompt embeddings around the fp32 block
+        half = int(tensors[2].dtype == torch.float16)
+        m = native.UptMixer(P, dt, dv, D, half, 0, *[t.data_ptr() for t in ts])
         native.check(lib.grip_upt_mixer_forward(byref(m), _ptr(coop_out), _ptr(vpt_out), _ptr(ws), ws.numel(), _stream()))
         ctx.save_for_backward(*ts)
-        ctx.ws, ctx.dims = ws, (P, dt, dv, D)
+        ctx.ws, ctx.dims, ctx.half = ws, (P, dt, dv, D), half
         ctx.shapes = [t.shape for t in tensors]
         ctx.dtypes = [t.dtype for t in tensors]
         return coop_out, vpt_out
@@ -483,8 +485,8 @@ class UptMixerFn(torch.autograd.Function):
         d_coop = torch.zeros(P, dt, device=dev) if d_coop is None else d_coop.contiguous().float()
         d_vpt = torch.zeros(P, dv, device=dev) if d_vpt is None else d_vpt.contiguous().float()
         grads = [torch.empty_like(t) for t in ts]
-        m = native.UptMixer(P, dt, dv, D, *[t.data_ptr() for t in ts])
-        g = native.UptMixer(P, dt, dv, D, *[t.data_ptr() for t in grads])
+        m = native.UptMixer(P, dt, dv, D, ctx.half, 0, *[t.data_ptr() for t in ts])
+        g = native.UptMixer(P, dt, dv, D, ctx.half, 0, *[t.data_ptr() for t in grads])
         native.check(lib.grip_upt_mixer_backward(byref(m), _ptr(d_coop), _ptr(d_vpt), byref(g), _ptr(ctx.ws), ctx.ws.numel(), _stream()))
         return tuple(gr.reshape(sh).to(dtp) for gr, sh, dtp in zip(grads, ctx.shapes, ctx.dtypes))
 

@@ -77,11 +77,14 @@ class UPTModel(_ModuleShim, nn.Module):
         self.text_encoder = text_encoder
 
     def _native_mixer_ok(self):
-        """The native mixer covers what the reference builds (:99-119): float32 parameters, one block, one head, on the GPU.  The
-        float16 branch (multimodal_prompt.py:46) and any other shape run the same arithmetic through the framework's kernels."""
+        """The native mixer covers what the reference builds (:99-119): one block, one head, on the GPU, float32 -- or the float16 branch
+        of multimodal_prompt.py:46 (fp16 prompt embeddings and projection Linears around the fp32 block: the same kernels with fp16 rounding
+        points, grip_upt_mixer.half_linears).  Any other shape runs the same arithmetic through the framework's kernels."""
         import os
         t = self.transformer
-        return (self.dtype == torch.float32 and self.coop_embeddings.is_cuda and os.environ.get("GRIP_NATIVE_MIXER", "1") != "0"
+        dtypes_ok = all(p.dtype == self.dtype for p in (self.coop_embeddings, self.vpt_embeddings, self.proj_coop_pre.weight, self.proj_vpt_post.weight)) \
+            and t.resblocks[0].ln_1.weight.dtype == torch.float32
+        return (self.dtype in (torch.float32, torch.float16) and dtypes_ok and self.coop_embeddings.is_cuda and os.environ.get("GRIP_NATIVE_MIXER", "1") != "0"
                 and getattr(t, "layers", 0) == 1 and t.resblocks[0].attn.num_heads == 1 and len(self.coop_embeddings) == 1
                 and self.coop_length == self.vpt_length and self.coop_length <= 16 and t.width % 64 == 0 and t.width <= 256)
 
@@ -95,7 +98,7 @@ class UPTModel(_ModuleShim, nn.Module):
                 self.proj_vpt_pre.bias, b.ln_1.weight, b.ln_1.bias, b.attn.in_proj_weight, b.attn.in_proj_bias, b.attn.out_proj.weight,
                 b.attn.out_proj.bias, b.ln_2.weight, b.ln_2.bias, b.mlp.c_fc.weight, b.mlp.c_fc.bias, b.mlp.c_proj.weight, b.mlp.c_proj.bias,
                 self.proj_coop_post.weight, self.proj_coop_post.bias, self.proj_vpt_post.weight, self.proj_vpt_post.bias)
-            return coop_embs.reshape(-1, self.coop_length, self.coop_dim), vpt_embs.reshape(-1, self.vpt_length, self.vpt_dim)
+            return (coop_embs.reshape(-1, self.coop_length, self.coop_dim).to(self.dtype), vpt_embs.reshape(-1, self.vpt_length, self.vpt_dim).to(self.dtype))
         coop = self.proj_coop_pre(self.coop_embeddings)
         vpt = self.proj_vpt_pre(self.vpt_embeddings)
         seq = torch.cat((coop, vpt), dim=0).to(torch.float32)

@@ -41,7 +41,7 @@ MIXER_TENSORS = ("coop", "vpt", "coop_pre_w", "coop_pre_b", "vpt_pre_w", "vpt_pr
 
 class UptMixer(ctypes.Structure):
     """grip_upt_mixer (include/grip_amd.h)."""
-    _fields_ = [(n, c_int32) for n in ("n_prompt", "text_width", "vision_width", "dim")] + [(n, c_void_p) for n in MIXER_TENSORS]
+    _fields_ = [(n, c_int32) for n in ("n_prompt", "text_width", "vision_width", "dim", "half_linears", "reserved_")] + [(n, c_void_p) for n in MIXER_TENSORS]
 
 
 _SIGS = {

@@ -84,6 +84,21 @@ def test_assign_pseudo_labels_returns_the_reference_lists(tmp_path, monkeypatch,
         print(f"{group}.{modality}: {st['rows_refined']} of {st['rows']} rows refined, bound {st['eps']:.2e}")
 
 
+@pytest.mark.parametrize("group,modality", [("small", "multi"), ("small", "image"), ("vitb16", "text"), ("vitb16", "multi")])
+def test_three_tier_refinement_returns_the_reference_lists(tmp_path, monkeypatch, group, modality):
+    """The same fixtures through the THREE-tier path (GRIP_SPLIT_TIER=1 forces the split-f16 middle tier, which pools this small would skip):
+    f16 screen -> split-f16 tower -> f32 tower, trained prompts in all three towers; still the reference's lists."""
+    from grip_amd import pseudolabels as pl
+    monkeypatch.setenv("GRIP_SPLIT_TIER", "1")
+    fx = _fixture(group)
+    m, data, meta = _strategy(fx, modality, monkeypatch, tmp_path, False)
+    out = m.assign_pseudo_labels(meta["k"], data)
+    st = pl.LAST_REFINE_STATS
+    print(f"{group}.{modality}: {st['rows_mid']} split-f16 rows, {st['rows_exact']} f32 rows, bounds {st['eps']:.2e} / {st['eps_mid']:.2e}")
+    assert (list(out.filepaths), [int(x) for x in out.labels]) == tuple(meta["lists"])
+    assert st["tiers"] == 3 and st["rows_mid"] > 0 and st["eps_mid"] < st["eps"]
+
+
 @pytest.mark.parametrize("group", ["small", "vitb16"])
 @pytest.mark.parametrize("modality", ["multi", "text", "image"])
 def test_trained_prompt_probabilities_match_the_reference(tmp_path, monkeypatch, group, modality):

@@ -122,32 +122,44 @@ def test_upt_model_float16_branch(monkeypatch):
     vpt = (torch.randn(1, 4, 256, generator=g) * 0.02).half()
     res = {}
     trainable = lambda mod: [(n, p) for n, p in mod.named_parameters() if p.requires_grad]      # noqa: E731  (the frozen towers hang off the model too)
-    for dtype in (torch.float16, torch.float32):
+    for key, dtype, native_mixer in (("f16", torch.float16, "1"), ("f16_framework", torch.float16, "0"), ("f32", torch.float32, "1")):
+        monkeypatch.setenv("GRIP_NATIVE_MIXER", native_mixer)
         torch.manual_seed(11)
         um = UPTModel(coop.to(dtype).cuda(), vpt.to(dtype).cuda(), None, CustomImageEncoder(cm.visual), CustomTextEncoder(cm, "cuda", dtype), classes, 128,
                       device="cuda", dtype=dtype)
-        if dtype == torch.float32:      # the same parameter values as the float16 model
+        if key != "f16":      # the same parameter values as the float16 model
             with torch.no_grad():
                 for (n, p), (_, q) in zip(trainable(um), res["f16_params"]):
-                    p.copy_(q.float())
+                    p.copy_(q.to(p.dtype))
         else:
             res["f16_params"] = [(n, p.detach().clone()) for n, p in trainable(um)]
             assert um.proj_coop_pre.weight.dtype == torch.float16 and um.transformer.resblocks[0].ln_1.weight.dtype == torch.float32
-            assert not um._native_mixer_ok()
+        # r04: the float16 branch runs on csrc/mixer.hip too (grip_upt_mixer.half_linears); GRIP_NATIVE_MIXER=0 = the framework's kernels
+        assert um._native_mixer_ok() == (native_mixer == "1")
         t_out, v_out = um(x, classes)
         assert t_out.dtype == torch.float32 and v_out.shape == (6, cm.visual.output_dim)
         logits = CosineHeadFn.apply(v_out, t_out, 100.0)
         loss = WeightedCEFn.apply(logits, torch.arange(6, device="cuda") % 4, torch.full((6,), 1 / 6, device="cuda"))
         loss.backward()
-        res[dtype] = (t_out.detach(), v_out.detach(), loss.item(), {n: p.grad.detach().float().clone() for n, p in trainable(um)})
-        assert len(res[dtype][3]) == 22
+        res[key] = (t_out.detach(), v_out.detach(), loss.item(), {n: p.grad.detach().float().clone() for n, p in trainable(um)})
+        assert len(res[key][3]) == 22
         for n, p in trainable(um):
             assert p.grad is not None and p.grad.dtype == p.dtype and torch.isfinite(p.grad).all(), n
-    h, f = res[torch.float16], res[torch.float32]
+    cos = torch.nn.functional.cosine_similarity
+    h, hf, f = res["f16"], res["f16_framework"], res["f32"]
+    # native float16 branch against the framework's float16 branch: the same rounding points, different summation orders inside the fp16 Linears
+    for a, b in ((h[0], hf[0]), (h[1], hf[1])):
+        assert cos(a, b, dim=-1).min().item() >= 1 - 1e-5
+    assert abs(h[2] - hf[2]) <= 2e-3 * max(1.0, abs(hf[2]))
+    for n in hf[3]:
+        if hf[3][n].norm().item() > 1e-6:
+            c = cos(h[3][n].reshape(-1), hf[3][n].reshape(-1), dim=0).item()
+            assert c >= 0.995, (n, c)
+    # ... and against the float32 model with the same (fp16-representable) parameters
     for a, b in ((h[0], f[0]), (h[1], f[1])):
-        assert torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item() >= 1 - 1e-4
+        assert cos(a, b, dim=-1).min().item() >= 1 - 1e-4
     assert abs(h[2] - f[2]) <= 2e-2 * max(1.0, abs(f[2]))
     for n in f[3]:
         if f[3][n].norm().item() > 1e-6:      # fp16 gradients of tiny magnitude lose bits; compare direction where there is a signal
-            cos = torch.nn.functional.cosine_similarity(h[3][n].reshape(-1), f[3][n].reshape(-1), dim=0).item()
-            assert cos >= 0.98, (n, cos)
+            c = cos(h[3][n].reshape(-1), f[3][n].reshape(-1), dim=0).item()
+            assert c >= 0.98, (n, c)

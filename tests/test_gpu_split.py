@@ -126,7 +126,7 @@ def test_split_gemm_is_deterministic_and_row_independent():
     assert torch.equal(o3, out[700:800])
 
 
-@pytest.mark.parametrize("name,n,res", [("small", 96, 64), ("ViT-B/16", 48, 224)])
+@pytest.mark.parametrize("name,n,res", [("small", 96, 64), ("ViT-B/16", 48, 224), ("ViT-L/14@336px", 6, 336)])      # (S = 577: f32 attention, split output)
 def test_split_tower_tracks_the_exact_twin(name, n, res):
     """Embeddings of the split-f16 vision tower against the f32 twin's on the same structured images (with and without a visual prompt):
     two orders of magnitude closer than the f16 tower's, and chunking-independent bit for bit."""
