@@ -49,19 +49,29 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     const int q_min = (Ps > 0 && b > 0) ? Ps : 0;
     auto R = [&](int r) { return seq_row(b, r, S, Ps); };
 
-    for (int idx = tid; idx < SP * 8; idx += NWB * 64) {
-        const int row = idx >> 3, chunk = idx & 7;
-        half8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < S) {
-            const half_t* rp = base + R(row) * ld;
-            kv = *(const half8*)(rp + D + chunk * 8);
-            vv = *(const half8*)(rp + 2 * D + chunk * 8);
+    // A thread takes a PAIR of rows (2 r, 2 r + 1) and one 8-wide slice: the transposed images hold two consecutive keys of a head dim in one 32-bit
+    // word (vt_index), so they are written as eight 4-byte words instead of sixteen 2-byte ones (r04: the 2-byte writes were the 39 % LDS bank
+    // conflicts of profiles/r03_sq_vpt.csv), the forward's V staging pattern.
+    for (int idx = tid; idx < (SP / 2) * 8; idx += NWB * 64) {
+        const int r0 = 2 * (idx >> 3), chunk = idx & 7;
+        half8 k0 = {0, 0, 0, 0, 0, 0, 0, 0}, k1 = k0, v0 = k0, v1 = k0;
+        if (r0 < S) {
+            const half_t* rp = base + R(r0) * ld;
+            k0 = *(const half8*)(rp + D + chunk * 8);
+            v0 = *(const half8*)(rp + 2 * D + chunk * 8);
         }
-        const int sw = (chunk ^ (row & 7)) * 8;
-        *(half8*)(Ks + row * 64 + sw) = kv;
-        *(half8*)(Vs + row * 64 + sw) = vv;
+        if (r0 + 1 < S) {
+            const half_t* rp = base + R(r0 + 1) * ld;
+            k1 = *(const half8*)(rp + D + chunk * 8);
+            v1 = *(const half8*)(rp + 2 * D + chunk * 8);
+        }
+        const int sw0 = (chunk ^ (r0 & 7)) * 8, sw1 = (chunk ^ ((r0 + 1) & 7)) * 8;
+        *(half8*)(Ks + r0 * 64 + sw0) = k0;
+        *(half8*)(Ks + (r0 + 1) * 64 + sw1) = k1;
+        *(half8*)(Vs + r0 * 64 + sw0) = v0;
+        *(half8*)(Vs + (r0 + 1) * 64 + sw1) = v1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) T0[vt_index(row, chunk * 8 + j)] = kv[j];
+        for (int j = 0; j < 8; ++j) *(half2v*)(T0 + vt_index(r0, chunk * 8 + j)) = (half2v){k0[j], k1[j]};
     }
     __syncthreads();
 
@@ -161,18 +171,23 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     }
     __syncthreads();
     // ------------------------------------------------------------------ restage: T0 = (Q/8)^T, T1 = dO^T
-    for (int idx = tid; idx < SP * 8; idx += NWB * 64) {
-        const int row = idx >> 3, chunk = idx & 7;
-        half8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, dv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < S && row >= q_min) {      // (queries below q_min are not this sequence's: zero rows add nothing to dK / dV)
-            qv = *(const half8*)(base + R(row) * ld + chunk * 8);
-            qv *= (half_t)0.125f;
-            dv = *(const half8*)(dobase + R(row) * D + chunk * 8);
+    for (int idx = tid; idx < (SP / 2) * 8; idx += NWB * 64) {
+        const int r0 = 2 * (idx >> 3), chunk = idx & 7;
+        half8 q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, d0 = q0, d1 = q0;
+        if (r0 < S && r0 >= q_min) {      // (queries below q_min are not this sequence's: zero rows add nothing to dK / dV)
+            q0 = *(const half8*)(base + R(r0) * ld + chunk * 8);
+            q0 *= (half_t)0.125f;
+            d0 = *(const half8*)(dobase + R(r0) * D + chunk * 8);
+        }
+        if (r0 + 1 < S && r0 + 1 >= q_min) {
+            q1 = *(const half8*)(base + R(r0 + 1) * ld + chunk * 8);
+            q1 *= (half_t)0.125f;
+            d1 = *(const half8*)(dobase + R(r0 + 1) * D + chunk * 8);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            T0[vt_index(row, chunk * 8 + j)] = qv[j];
-            T1[vt_index(row, chunk * 8 + j)] = dv[j];
+            *(half2v*)(T0 + vt_index(r0, chunk * 8 + j)) = (half2v){q0[j], q1[j]};
+            *(half2v*)(T1 + vt_index(r0, chunk * 8 + j)) = (half2v){d0[j], d1[j]};
         }
     }
     __syncthreads();
