@@ -109,12 +109,14 @@ int grip_workspace_bytes(const grip_tower* t, int batch, int n_prefix, int seq_l
  *   prefix     [n_prefix, width] f32, or NULL when n_prefix == 0; inserted between CLS and the
  *              patches after the positional embedding, shared by the whole batch
  *   out_emb    [batch, embed_dim] f32 (un-normalised, as the reference returns it)
- *   generation NULL, or receives the number of this train-mode forward (0 for train = 0).  Several train-mode forwards may
+ *   flags      GRIP_FWD_TRAIN (= the `train` argument of earlier ABIs: 1 keeps the activations backward needs) and / or
+ *              GRIP_FWD_NO_POS_EMB (forward(..., pos_emb=False), :141: CLS and patches without the positional embedding)
+ *   generation NULL, or receives the number of this train-mode forward (0 without GRIP_FWD_TRAIN).  Several train-mode forwards may
  *              be outstanding, each on its own workspace; a second one on the SAME workspace overwrites the first one's
  *              saved activations, and a backward that presents the first one's number then fails with GRIP_ERR_STATE.
  */
 int grip_vit_forward(grip_tower* t, const void* images, int images_f16, const float* prefix, int n_prefix,
-                     int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream);
+                     int batch, float* out_emb, void* workspace, size_t workspace_bytes, int flags, uint64_t* generation, void* stream);
 
 /* Input-gradient chain of the frozen ViT down to the prompt slice (autograd of the above w.r.t.
  * image_prefix only; no weight gradients exist).  Must follow a train-mode forward on the same
@@ -141,9 +143,11 @@ int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* 
  *              class positions attend to the shared keys and their own, and the backward adds every class's share of
  *              the shared keys' gradient in class order.  Embeddings and prompt gradient are the same function of the
  *              inputs; ignored (plain layout) when prefix_classes != 1, n_prefix == 0 or dims.precision != 0.
+ *              GRIP_FWD_NO_POS_EMB: CustomTextEncoder.forward(enable_pos_emb=False), x = token / prompt embeddings only.
  */
 #define GRIP_FWD_TRAIN 1
 #define GRIP_FWD_SHARED_PREFIX 2
+#define GRIP_FWD_NO_POS_EMB 4 /* models/clip_encoders.py:70-74, enable_pos_emb=False: the positional embedding is not added */
 int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
                       int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
                       void* workspace, size_t workspace_bytes, int flags, uint64_t* generation, void* stream);

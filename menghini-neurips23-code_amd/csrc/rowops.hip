@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
     f32x4 v[NV];
     const f32x4* src;
     const f32x4* add = nullptr;
-    if (s == 0) { src = (const f32x4*)cls; add = (const f32x4*)pos; }
+    if (s == 0) { src = (const f32x4*)cls; add = (const f32x4*)pos; }     // pos == nullptr: pos_emb=False (models/clip_encoders.py:141)
     else if (s <= P) { src = (const f32x4*)(prefix + (size_t)(s - 1) * d); }
-    else { const int j = s - 1 - P; src = (const f32x4*)(patch_out + ((size_t)b * G2 + j) * d); add = (const f32x4*)(pos + (size_t)(1 + j) * d); }
+    else { const int j = s - 1 - P; src = (const f32x4*)(patch_out + ((size_t)b * G2 + j) * d); add = pos ? (const f32x4*)(pos + (size_t)(1 + j) * d) : nullptr; }
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
@@ -139,7 +139,8 @@ int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float
 }
 
 // ------------------------------------------------------------------------------------------------
-// Text embedding (models/clip_encoders.py:63-74): x[c, t] = (1 <= t <= P ? prefix[c or 0, t-1] : tok_emb[ids[c, t]]) + pos[t]
+// Text embedding (models/clip_encoders.py:63-74): x[c, t] = (1 <= t <= P ? prefix[c or 0, t-1] : tok_emb[ids[c, t]]) + pos[t];
+// pos == nullptr is the reference's enable_pos_emb=False branch (:70-74): no positional term.
 template <typename RT>
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, int ld_ids, const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, const float* __restrict__ prefix, int P,
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restri
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         src = (const f32x4*)(tok_emb + (size_t)id * d);
     }
-    const f32x4* pp = (const f32x4*)(pos + (size_t)t * d);
+    const f32x4* pp = pos ? (const f32x4*)(pos + (size_t)t * d) : nullptr;
     RT* o = x + (size_t)row * d;
     float sm = 0.f, sq = 0.f;
     for (int f = lane; f < d4; f += 64) {
-        const f32x4 v = src[f] + pp[f];
+        const f32x4 v = pp ? src[f] + pp[f] : src[f];
         store4(o, f, v);
         sm += (v[0] + v[1]) + (v[2] + v[3]);
         sq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];

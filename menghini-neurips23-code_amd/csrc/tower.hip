@@ -554,9 +554,11 @@ static void note_forward(grip_tower* t, void* workspace, int train, const Worksp
 }
 
 extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f16, const float* prefix, int n_prefix,
-                                int batch, float* out_emb, void* workspace, size_t workspace_bytes, int train, uint64_t* generation, void* stream) {
+                                int batch, float* out_emb, void* workspace, size_t workspace_bytes, int flags, uint64_t* generation, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 0, "vit_forward: not a vision tower");
+        GRIP_REQUIRE((flags & ~(GRIP_FWD_TRAIN | GRIP_FWD_NO_POS_EMB)) == 0, "vit_forward: unknown flag bits 0x%x", flags);
+        const int train = flags & GRIP_FWD_TRAIN;
         GRIP_REQUIRE(images && out_emb && (n_prefix == 0 || prefix), "vit_forward: null pointer");
         Workspace w;
         RUN(check_ws(t, batch, n_prefix, train, workspace, workspace_bytes, w));
@@ -569,7 +571,7 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         a.f32 = f; a.A = w.patches; a.W = t->wop(t->L.conv_w); a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, train ? nullptr : w.rowstat, batch, G2, d, s));
+        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, train ? nullptr : w.rowstat, batch, G2, d, s));
         resid_t* xf = nullptr;
         bool compact = false;
         RUN(run_blocks(t, w, x0, /*causal=*/0, nullptr, s, &xf, &compact));
@@ -589,7 +591,7 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         GRIP_REQUIRE(t && t->D.kind == 1, "text_forward: not a text tower");
         GRIP_REQUIRE(token_ids && eot_index && out_emb && (n_prefix == 0 || prefix), "text_forward: null pointer");
         GRIP_REQUIRE(n_prefix == 0 || prefix_classes == 1 || prefix_classes == n_class, "text_forward: prefix_classes must be 1 or n_class");
-        GRIP_REQUIRE((flags & ~(GRIP_FWD_TRAIN | GRIP_FWD_SHARED_PREFIX)) == 0, "text_forward: unknown flag bits 0x%x", flags);
+        GRIP_REQUIRE((flags & ~(GRIP_FWD_TRAIN | GRIP_FWD_SHARED_PREFIX | GRIP_FWD_NO_POS_EMB)) == 0, "text_forward: unknown flag bits 0x%x", flags);
         const int train = flags & GRIP_FWD_TRAIN;
         // the caller vouches for identical tokens at positions 0 .. n_prefix in every class; exact (f32) towers keep the plain layout
         const int shared = (flags & GRIP_FWD_SHARED_PREFIX) && n_prefix > 0 && prefix_classes == 1 && !t->f32;
@@ -600,7 +602,7 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         const int d = D.width, f = t->f32;
         const float* F = t->w32;
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, train ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s, w.Ps));
+        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, train ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s, w.Ps));
         resid_t* xf = nullptr;
         bool compact = false;
         RUN(run_blocks(t, w, x0, /*causal=*/1, eot_index, s, &xf, &compact));

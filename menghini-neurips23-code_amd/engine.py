@@ -169,7 +169,7 @@ class Tower:
         return c_void_p(ws.data_ptr() + off), ws.numel() - off
 
     # ---- forward / backward
-    def vit_forward(self, images, prefix=None, train=False):
+    def vit_forward(self, images, prefix=None, train=False, pos_emb=True):
         if not self._finalized:
             self.finalize()
         assert self.kind == 0
@@ -185,7 +185,8 @@ class Tower:
         p, n = self._aligned(ws)
         gen = c_uint64(0)
         native.check(self.lib.grip_vit_forward(self.handle, _ptr(images), int(images.dtype == torch.float16), _ptr(prefix), P, B,
-                                               _ptr(out), p, n, int(train), byref(gen), _stream()))
+                                               _ptr(out), p, n, (native.FWD_TRAIN if train else 0) | (0 if pos_emb else native.FWD_NO_POS_EMB),
+                                               byref(gen), _stream()))
         ws.generation = gen.value
         return out, ws
 
@@ -245,7 +246,7 @@ class Tower:
     # read, so later positions cannot influence any output (exact; the reference encodes all 77).
     truncate_text_at_eot = True
 
-    def text_forward(self, token_ids, prefix=None, train=False, seq_len=None):
+    def text_forward(self, token_ids, prefix=None, train=False, seq_len=None, pos_emb=True):
         if not self._finalized:
             self.finalize()
         assert self.kind == 1
@@ -265,7 +266,7 @@ class Tower:
         if prefix is not None:
             pc, P = prefix.shape[0], prefix.shape[1]
             prefix = prefix.contiguous().float()
-        flags = native.FWD_TRAIN if train else 0
+        flags = (native.FWD_TRAIN if train else 0) | (0 if pos_emb else native.FWD_NO_POS_EMB)
         if P and pc == 1 and not self.exact and self.share_text_prefix and self._shares_prefix(token_ids, ids, eot, P):
             flags |= native.FWD_SHARED_PREFIX
         self.last_text_flags = flags
@@ -317,11 +318,11 @@ class VitPrefixFn(torch.autograd.Function):
     """CustomVisionTransformer.forward with autograd to the visual prompt only (frozen backbone)."""
 
     @staticmethod
-    def forward(ctx, tower, images, prefix):
+    def forward(ctx, tower, images, prefix, pos_emb=True):
         need = ctx.needs_input_grad[2]   # grad mode is off inside Function.forward
         if need and tower.exact:
             raise native.GripError("exact (f32) towers are inference-only: prompt gradients need a default-precision tower")
-        out, ws = tower.vit_forward(images, prefix.detach(), train=need)
+        out, ws = tower.vit_forward(images, prefix.detach(), train=need, pos_emb=pos_emb)
         ctx.tower, ctx.ws, ctx.generation = tower, ws, ws.generation
         if need:
             tower.hold(ws, ctx)
@@ -334,19 +335,19 @@ class VitPrefixFn(torch.autograd.Function):
         (prefix,) = ctx.saved_tensors
         g = ctx.tower.vit_backward(grad_out, prefix, ctx.ws, ctx.generation)
         ctx.tower.release(ctx.ws)
-        return None, None, g.reshape(ctx.pshape).to(ctx.pdtype)
+        return None, None, g.reshape(ctx.pshape).to(ctx.pdtype), None
 
 
 class TextPrefixFn(torch.autograd.Function):
     """CustomTextEncoder.forward with autograd to the textual prompt only."""
 
     @staticmethod
-    def forward(ctx, tower, token_ids, prefix):
+    def forward(ctx, tower, token_ids, prefix, pos_emb=True):
         need = ctx.needs_input_grad[2]
         if need and tower.exact:
             raise native.GripError("exact (f32) towers are inference-only: prompt gradients need a default-precision tower")
         cached = getattr(token_ids, "_grip_seq_len", None)
-        out, ws, keep = tower.text_forward(token_ids, prefix.detach(), train=need, seq_len=cached)
+        out, ws, keep = tower.text_forward(token_ids, prefix.detach(), train=need, seq_len=cached, pos_emb=pos_emb)
         token_ids._grip_seq_len = keep[2]
         ctx.tower, ctx.ws, ctx.generation = tower, ws, ws.generation
         if need:
@@ -359,25 +360,26 @@ class TextPrefixFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         g = ctx.tower.text_backward(grad_out, tuple(ctx.pshape), ctx.ws, ctx.generation)
         ctx.tower.release(ctx.ws)
-        return None, None, g.to(ctx.pdtype)
+        return None, None, g.to(ctx.pdtype), None
 
 
-def vit_prefix_forward(tower, images, prefix):
+def vit_prefix_forward(tower, images, prefix, pos_emb=True):
     """CustomVisionTransformer.forward on the native tower.  The train-mode forward (activations saved for the prompt
     gradient) runs only when a gradient can actually be asked for: grad mode on AND the prompt requires grad.  Under
     torch.no_grad() -- validation, test predictions, the pseudolabel passes -- it is the plain inference forward, the same
     arithmetic as the pool encode (autograd's needs_input_grad alone does not see the surrounding no_grad)."""
     if torch.is_grad_enabled() and prefix.requires_grad:
-        return VitPrefixFn.apply(tower, images, prefix)
-    return tower.vit_forward(images, prefix.detach(), train=False)[0]
+        return VitPrefixFn.apply(tower, images, prefix, pos_emb)
+    return tower.vit_forward(images, prefix.detach(), train=False, pos_emb=pos_emb)[0]
 
 
-def text_prefix_forward(tower, token_ids, prefix):
-    """CustomTextEncoder.forward on the native tower; see vit_prefix_forward."""
+def text_prefix_forward(tower, token_ids, prefix, pos_emb=True):
+    """CustomTextEncoder.forward on the native tower; see vit_prefix_forward.  pos_emb=False is the reference's enable_pos_emb=False
+    branch (models/clip_encoders.py:70-74): the positional embedding is not added (the positions' gradient path is untouched: it is additive)."""
     if torch.is_grad_enabled() and prefix.requires_grad:
-        return TextPrefixFn.apply(tower, token_ids, prefix)
+        return TextPrefixFn.apply(tower, token_ids, prefix, pos_emb)
     cached = getattr(token_ids, "_grip_seq_len", None)
-    out, _, keep = tower.text_forward(token_ids, prefix.detach(), train=False, seq_len=cached)
+    out, _, keep = tower.text_forward(token_ids, prefix.detach(), train=False, seq_len=cached, pos_emb=pos_emb)
     token_ids._grip_seq_len = keep[2]
     return out
 

@@ -53,10 +53,8 @@ class CustomTextEncoder(nn.Module):
         return ids
 
     def forward(self, class_embeddings, classes, enable_pos_emb=True):
-        if not enable_pos_emb:
-            raise NotImplementedError("enable_pos_emb=False is never used by the reference")
         token_ids = self._token_ids(class_embeddings.size()[1], classes)
-        return text_prefix_forward(self.clip_model.text_tower, token_ids, class_embeddings)
+        return text_prefix_forward(self.clip_model.text_tower, token_ids, class_embeddings, pos_emb=bool(enable_pos_emb))   # :70-74
 
 
 class ImageEncoder(nn.Module):
@@ -87,9 +85,11 @@ class CustomVisionTransformer(nn.Module):
         self._vt = [vision_transformer]
 
     def forward(self, x, image_prefix, pos_emb=True, deep_embs=None):
-        if deep_embs is not None or not pos_emb:
-            raise NotImplementedError("deep prompts / pos_emb=False are dead code in the reference (VPT_DEEP: False)")
-        return vit_prefix_forward(self._vt[0].tower, x, image_prefix)
+        if deep_embs is not None:
+            # reference :158-174 reads self.visual / self.mvlpt_model, attributes this class never has: the branch raises
+            # AttributeError upstream as well (VPT_DEEP is False in every config)
+            raise NotImplementedError("deep prompts are unreachable in the reference (VPT_DEEP: False; :158-174 reads attributes that do not exist)")
+        return vit_prefix_forward(self._vt[0].tower, x, image_prefix, pos_emb=bool(pos_emb))   # :141
 
 
 class CustomImageEncoder(nn.Module):

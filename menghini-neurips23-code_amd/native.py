@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRIP_LIB") or os.path.join(_HERE, "libgrip_amd.so")      # GRIP_LIB: another build of the same ABI (developer A/B)
 ABI_VERSION = 6
-FWD_TRAIN, FWD_SHARED_PREFIX = 1, 2      # grip_text_forward flags
+FWD_TRAIN, FWD_SHARED_PREFIX, FWD_NO_POS_EMB = 1, 2, 4      # grip_text_forward flags
 
 
 class GripError(RuntimeError):

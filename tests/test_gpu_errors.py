@@ -107,6 +107,11 @@ def test_bad_arguments_are_rejected(model):
         tt.text_forward(ids.cuda(), torch.zeros(2, 4, 128, device="cuda"))  # prefix for 2 classes, 3 prompts
     with pytest.raises(native.GripError, match="not a vision tower"):
         native.check(tt.lib.grip_vit_forward(tt.handle, None, 0, None, 0, 1, None, None, 0, 0, None, None))
+    ws = t.workspace(2, 0, False)
+    p, n = t._aligned(ws)
+    out = torch.empty(2, t.embed_dim, device="cuda")
+    with pytest.raises(native.GripError, match="unknown flag bits"):
+        native.check(t.lib.grip_vit_forward(t.handle, x.data_ptr(), 0, None, 0, 2, out.data_ptr(), p, n, 8, None, None))
     with pytest.raises(NotImplementedError):
         from grip_amd.models import CustomImageEncoder
         CustomImageEncoder(model.visual)(x, torch.zeros(2, 128, device="cuda"), deep_embds=torch.zeros(1))

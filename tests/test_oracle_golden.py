@@ -42,6 +42,24 @@ def test_vision_and_text_wrappers_match_golden(tiny, golden_small):
     np.testing.assert_allclose(vp.grad.numpy(), g["g1.vision_p3_grad_prefix"], rtol=1e-4, atol=1e-4)
 
 
+def test_wrappers_without_positional_embedding_match_golden():
+    """G10 (oracle/gen_golden_posemb.py): the enable_pos_emb=False / pos_emb=False branches, models/clip_encoders.py:70-74 and :141."""
+    from oracle import wrappers as W
+    g = np.load(os.path.join(REPO, "tests", "golden", "posemb.npz"))
+    m = oracle_clip().load("small")[0]
+    x = _inputs("px.s.x", (2, 3, 64, 64))
+    vp = _inputs("px.s.vprefix", (16, m.visual.conv1.weight.shape[0]), 0.02).requires_grad_(True)
+    tp = _inputs("px.s.tprefix", (1, 16, m.token_embedding.weight.shape[1]), 0.02).requires_grad_(True)
+    v = W.vision_forward(m.visual, x, vp, pos_emb=False)
+    t = W.text_forward(m, torch.from_numpy(g["px.s.tokens"]), tp, enable_pos_emb=False)
+    np.testing.assert_allclose(v.detach().numpy(), g["px.s.vision"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(t.detach().numpy(), g["px.s.text"], rtol=1e-5, atol=1e-5)
+    (v ** 2).sum().backward()
+    (t ** 2).sum().backward()
+    np.testing.assert_allclose(vp.grad.numpy(), g["px.s.vision_grad_prefix"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(tp.grad.numpy(), g["px.s.text_grad_prefix"], rtol=1e-4, atol=1e-4)
+
+
 def test_tokens_in_golden_come_from_the_stand_in_tokenizer(golden_small):
     from oracle import wrappers as W
     classes = ["forest", "annual crop land", "river", "sea lake", "highway"]
