@@ -20,6 +20,15 @@ int grip_debug_gemm(int epi, const void* A, const void* W, int M, int N, int K, 
  * the GEMM: out = [quickgelu](rstd_r (A W'^T - mean_r colsum) + bias) with rowstat [M, 2] = (mean, rstd), A = the raw rows. */
 int grip_debug_gemm_ln(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid, void* out, void* out2,
                        float* stat_part, const float* rowstat, const float* colsum, int m_pad, int variant, void* stream);
+/* The prompt-step forms of the text tower's train-mode forward (r04).  epi 7 / 8 with stat_in != NULL: the LayerNorm-folded GEMM reads the producer's
+ * stat_parts partial (sum, sum of squares) pairs ([stat_parts, M, 2]) instead of finalised statistics -- inside the kernel on the loader-wave kernels,
+ * through ln_stats_finalize into `rowstat` (writable, [M, 2]) otherwise.  epi 3 with ksplit > 1: cooperative split-K of the residual GEMM (partial tiles
+ * in coop_scratch, >= tiles_of_64x128 * ksplit * 32 KiB; tickets in coop_counter, 4 ints per tile, zero on entry and zero again on return).
+ * grip_debug_coop_split: the factor the tower would choose for this shape (1 = form not used). */
+int grip_debug_gemm_train(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid, void* out, void* out2,
+                          float* stat_part, float* rowstat, const float* colsum, const float* stat_in, int stat_parts, int ksplit,
+                          float* coop_scratch, int* coop_counter, int m_pad, void* stream);
+int grip_debug_coop_split(int M, int N, int K);
 /* Split-K product (the input-gradient GEMMs of the prompt steps): out = ksplit partial [M, N] f32 buffers, split_stride floats apart,
  * partial p = A[:, Kp] W[:, Kp]^T over the p-th K range.  ksplit = 0: the launcher's own choice; *ksplit_used receives the factor. */
 int grip_debug_gemm_splitk(const void* A, const void* W, int M, int N, int K, float* out, int ksplit, int64_t split_stride, int* ksplit_used,

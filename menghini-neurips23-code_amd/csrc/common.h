@@ -185,18 +185,28 @@ struct GemmArgs {
     float* stat_part;      // EPI_BIAS_RESID, optional: [N/64, M, 2] per-row partial (sum, sum of squares) of the values written, one pair
                            // per 64-column wave tile; ln_stats_finalize turns them into rowstat for the consuming GEMM
     const float* rowstat;  // EPI_LNFOLD_*: [M, 2] (mean, rstd) of A's rows
+    const float* stat_in;  // EPI_LNFOLD_*, optional: the producer's stat_part array ([stat_parts, M, 2]) when nobody has finalised it yet.  The loader-wave
+    int stat_parts;        // kernels (gemm_ringw_kernel) add the pairs themselves -- same order and arithmetic as ln_stats_finalize -- so a prompt step pays
+                           // no launch for it; for any other kernel the launcher runs ln_stats_finalize into `rowstat` (which must then be writable) first
     const float* colsum;   // EPI_LNFOLD_*: [N]
     // Split-K (EPI_F32 on the small-M kernels only): ksplit > 1 launches ksplit workgroups per output tile, each contracting
     // K/ksplit and writing its partial product to out + split * split_stride (floats); the consumer sums the partials
     // in a fixed order (launch_ln_bwd_add).  gemm_pick_ksplit chooses the factor.
     int ksplit;
     int64_t split_stride;
+    // Cooperative split-K (EPI_BIAS_RESID[_STATS] on gemm_ringw_kernel, 64-row tiles): ksplit > 1 with these two set.  Every split writes its partial
+    // tile to coop_scratch ([tile][split][wave][2048] f32), the LAST wave to arrive at a (tile, wave) counter adds the partials in split order (a fixed
+    // order whoever arrives last: deterministic) and runs the epilogue, then puts the counter back to zero.  For the K = 4 d GEMM of a few hundred rows
+    // (a text tower's c_proj: 28 tiles walking 32 K slices at the ~80 GB/s one CU stages).  coop_counter must be zero before the first such launch.
+    float* coop_scratch;
+    int* coop_counter;
     // One-tile-per-workgroup kernels: tile row tm starts its K walk rot_rows * tm slices further on (0: every tile row starts where its
     // column panel says).  Changes the summation order with the tile row, so only train-mode launches may set it (the inference
     // forwards stay bit-identical under any chunking).
     int rot_rows;
 };
 int gemm_pick_ksplit(int M, int N, int K);
+int gemm_pick_coop_split(int M, int N, int K);   // split factor of the cooperative form (1 = not worth it / not applicable)
 
 int launch_gemm(int epi, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);

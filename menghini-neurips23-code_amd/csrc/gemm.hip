@@ -23,6 +23,13 @@
 
 #include "common.h"
 
+// Synchronisation of the cooperative split-K form (gemm_ringw_kernel): 2 = system-scope cache bits on the partial tiles (default), 0 = device-scope fences,
+// 1 = plain accesses (developer A/B only: relies on workgroup placement)
+#ifndef GRIP_COOP_MODE
+#define GRIP_COOP_MODE 2
+#endif
+
+
 // Sub-step 1 of the persistent GEMM places its 12 fragment reads after MFMA pairs GRIP_RD0 .. GRIP_RD0 + 11 of the 16.  The compiler
 // puts a second s_waitcnt lgkmcnt(0) before the fifth MFMA of the block; with the reads starting at pair 0 that wait also drains the
 // two reads just issued.  Starting at pair 4 nothing newer is outstanding there: residual GEMM 1 038 -> 1 047 TF/s (0: 1 038, 2: 1 037).
@@ -118,7 +125,7 @@ __device__ __forceinline__ int slab_off(int row, int chunk) {
 // c_fc GEMMs 8 % against their plain-bias forms).
 template <int EPI, int ROWFRAGS, bool CHECK, int PF, bool PRE = false>
 __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane,
-                                                   const float2* pre = nullptr) {
+                                                   const float2* pre = nullptr, const f32x4* cb = nullptr) {
     constexpr int NP = ROWFRAGS / PF;
     constexpr int RP = 16 * PF;        // rows per pass
     constexpr int NI = 4 * PF;         // row groups (4 rows each) per pass
@@ -161,8 +168,13 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
     };
     f32x4 csum = {0.f, 0.f, 0.f, 0.f}, bfold = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FOLD) {
-        csum = *(const f32x4*)(g.colsum + col);
-        bfold = *(const f32x4*)(g.bias + col);
+        if (cb) {       // loaded by the caller before its K loop (colsum / folded bias of THIS lane's four columns)
+            csum = cb[0];
+            bfold = cb[1];
+        } else {
+            csum = *(const f32x4*)(g.colsum + col);
+            bfold = *(const f32x4*)(g.bias + col);
+        }
     }
     if constexpr (RESID || EPI == EPI_GELUGRAD_F16 || (FOLD && !PRE)) prefetch(0, 0);
 #pragma unroll
@@ -194,9 +206,9 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
             }
             float2 stp = make_float2(0.f, 0.f);
             if constexpr (FOLD && PRE) {      // cross-lane fetch with every lane active (outside the row guard below)
-                static_assert(!PRE || PF == 1, "preloaded statistics assume 16-row passes");
-                const int src = (((p & 3) * 16 + it * 4 + rr) << 2);       // lane holding row p*16 + it*4 + rr (mod 64), in bytes
-                const float2 pv = pre[p >> 2];
+                const int rloc = p * RP + it * 4 + rr;                     // row inside the wave's tile: lane rloc & 63 of pre[rloc >> 6] holds its pair
+                const int src = (rloc & 63) << 2;                          // (bytes)
+                const float2 pv = pre[rloc >> 6];
                 stp.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.x)));
                 stp.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pv.y)));
             }
@@ -236,11 +248,11 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
 
 template <int EPI, int ROWFRAGS, int PF = 2, bool PRE = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane,
-                                              const float2* pre = nullptr) {
+                                              const float2* pre = nullptr, const f32x4* cb = nullptr) {
     if (row0 + ROWFRAGS * 16 <= g.M)
-        epilogue_rows_impl<EPI, ROWFRAGS, false, PF, PRE>(g, acc, slab, row0, col0, lane, pre);
+        epilogue_rows_impl<EPI, ROWFRAGS, false, PF, PRE>(g, acc, slab, row0, col0, lane, pre, cb);
     else
-        epilogue_rows_impl<EPI, ROWFRAGS, true, PF, PRE>(g, acc, slab, row0, col0, lane, pre);
+        epilogue_rows_impl<EPI, ROWFRAGS, true, PF, PRE>(g, acc, slab, row0, col0, lane, pre, cb);
 }
 
 // ---- 16-byte-store form of the 16-row-pass epilogue (persistent kernel; the three f16-output epilogues of the pool encode).
@@ -745,6 +757,9 @@ __global__ __launch_bounds__(512) void gemm_ringw_kernel(GemmArgs g, int tiles_m
     int bid = blockIdx.x;
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        // (the cooperative split-K form pads gridDim.x to a multiple of 8, so that the splits of a tile -- linear workgroup ids gridDim.x apart --
+        // land on one XCD and meet in its L2; the padding workgroups leave here)
+        if (idx >= (xcd < r ? q + 1 : q)) return;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
@@ -754,12 +769,19 @@ __global__ __launch_bounds__(512) void gemm_ringw_kernel(GemmArgs g, int tiles_m
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    constexpr bool COOP = (EPI == EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_STATS) && WMF == 2;
     int nk = g.K / BK, kt0 = 0;                   // nk >= NST - 1 (launcher)
     if constexpr (EPI == EPI_F32) {
         if (gridDim.y > 1) {                      // split-K: k tiles [kt0, kt0 + nk) into partial buffer blockIdx.y
             nk /= (int)gridDim.y;
             kt0 = (int)blockIdx.y * nk;
             g.out = (float*)g.out + (size_t)blockIdx.y * (size_t)g.split_stride;
+        }
+    }
+    if constexpr (COOP) {
+        if (gridDim.y > 1) {                      // cooperative split-K (GemmArgs::coop_scratch): k tiles [kt0, kt0 + nk), partial tile to the scratch
+            nk /= (int)gridDim.y;
+            kt0 = (int)blockIdx.y * nk;
         }
     }
     const int rot = ((gridDim.y > 1 ? 0 : k_rot_cols(n0, g.N, nk)) + tm * g.rot_rows) % nk;
@@ -821,6 +843,41 @@ __global__ __launch_bounds__(512) void gemm_ringw_kernel(GemmArgs g, int tiles_m
     }
     f32x4 acc[WMF][4];
     init_acc<EPI, WMF>(g, acc, n0 + wc * 64, lane);
+    if constexpr (COOP) {
+        if (blockIdx.y > 0) {                         // the bias enters once, with split 0
+#pragma unroll
+            for (int i = 0; i < WMF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // LayerNorm-folded epilogues: (mean, rstd) of the wave's WMF x 16 rows, lane l <- row l, fetched a whole K loop ahead of their use -- from the
+    // finalised array, or straight from the producer's per-column-tile partial sums (GemmArgs::stat_in; ln_stats_finalize's order and arithmetic)
+    constexpr bool FOLD = (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16);
+    float2 pre[1] = {make_float2(0.f, 0.f)};
+    f32x4 cb[2] = {};
+    if constexpr (FOLD) {
+        static_assert(WMF * 16 <= 64, "one (mean, rstd) pair per lane");
+        cb[0] = *(const f32x4*)(g.colsum + n0 + wc * 64 + (lane & 15) * 4);      // epilogue_rows: a lane stores columns col0 + (lane & 15) * 4 .. + 3
+        cb[1] = *(const f32x4*)(g.bias + n0 + wc * 64 + (lane & 15) * 4);
+        int r = m0 + wr * WMF * 16 + (lane & (WMF * 16 - 1));
+        r = r < g.M ? r : g.M - 1;
+        if (g.stat_parts > 0) {
+            const float2* sp = (const float2*)g.stat_in + r;
+            float sm = 0.f, sq = 0.f;
+            for (int i = 0; i < g.stat_parts; ++i) {
+                const float2 v = sp[(size_t)i * g.M];
+                sm += v.x;
+                sq += v.y;
+            }
+            const float inv_d = 1.0f / (float)g.K;
+            const float mean = sm * inv_d;
+            const float var = fmaxf(sq * inv_d - mean * mean, 0.f);
+            pre[0] = make_float2(mean, rsqrtf(var + 1e-5f));
+        } else {
+            pre[0] = ((const float2*)g.rowstat)[r];
+        }
+    }
     half8 fa[2][WMF], fb[2][4];
     auto rd = [&](const half_t* st, int kk) {
 #pragma unroll
@@ -853,7 +910,75 @@ __global__ __launch_bounds__(512) void gemm_ringw_kernel(GemmArgs g, int tiles_m
         buf = nxt;
     }
     __builtin_amdgcn_s_barrier();   // every consumer is done with the ring: reuse it as epilogue slabs
-    epilogue_rows<EPI, WMF>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane);
+    if constexpr (COOP) {
+        if (gridDim.y > 1) {
+            const int nsplit = (int)gridDim.y;
+            constexpr int NF = WMF * 4;                                   // f32x4 per lane
+            f32x4* mine = (f32x4*)g.coop_scratch + ((size_t)(bid * nsplit + (int)blockIdx.y) * 4 + wave) * (NF * 64) + lane;
+            const f32x4* all = (const f32x4*)g.coop_scratch + ((size_t)(bid * nsplit) * 4 + wave) * (NF * 64) + lane;
+            (void)mine;
+            constexpr size_t SPLIT_STRIDE = (size_t)4 * NF * 64;
+            int old = 0;
+#if GRIP_COOP_MODE == 0
+            // release / acquire fences at device scope: on gfx950 a write-back of the XCD's whole dirty L2 per wave (measured: the GEMM 13 -> 23 us)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) mine[f * 64] = acc[f >> 2][f & 3];
+            __threadfence();
+            if (lane == 0) old = atomicAdd(g.coop_counter + bid * 4 + wave, 1);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != nsplit - 1) return;                                // not the last split of this (tile, wave): done
+            __threadfence();
+            auto ld = [&](const f32x4* p) { return *p; };
+#elif GRIP_COOP_MODE == 1
+            // plain stores, retired (= in the L2) before the ticket is drawn; plain loads.  Correct only while the splits of a tile share an XCD.
+#pragma unroll
+            for (int f = 0; f < NF; ++f) mine[f * 64] = acc[f >> 2][f & 3];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) old = __hip_atomic_fetch_add(g.coop_counter + bid * 4 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != nsplit - 1) return;
+            auto ld = [&](const f32x4* p) { return *p; };
+#else
+            // The partial tiles are stored WRITE-THROUGH (sc1) and read with sc1 loads (past the L1, served by the memory side), so they are coherent wherever
+            // the splits of a tile run and no fence is needed -- a device-scope release on gfx950 writes back the XCD's whole dirty L2 (measured: this GEMM
+            // 13 -> 23 us with __threadfence() per wave).  A store is retired (vmcnt) only when the memory side has it; the ticket is a relaxed device-scope
+            // atomic drawn after that.  (/opt/skills/guides/cdna_hip_programming.md, Guideline 16: "sc1 stores and loads both sides".)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const size_t scratch_bytes = (size_t)nwg * nsplit * 4 * NF * 64 * 16;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.coop_scratch, 0, (int)scratch_bytes, 0x00020000);
+            const uint32_t my_off = (uint32_t)(((size_t)(bid * nsplit + (int)blockIdx.y) * 4 + wave) * (NF * 64) + lane) * 16u;
+            const uint32_t all_off = (uint32_t)(((size_t)(bid * nsplit) * 4 + wave) * (NF * 64) + lane) * 16u;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[f >> 2][f & 3]), rsrc, (int)(my_off + f * 64 * 16), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) old = __hip_atomic_fetch_add(g.coop_counter + bid * 4 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != nsplit - 1) return;                                // not the last split of this (tile, wave): done
+            auto ld = [&](const f32x4* p) {
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(all_off + (uint32_t)(p - all) * 16u), 0, 16));
+            };
+#endif
+            // splits 0 .. nsplit - 1 in index order (this wave's own partial read back like the others), up to three splits in flight
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f >> 2][f & 3] = ld(all + f * 64);
+            for (int sp = 1; sp < nsplit; sp += 3) {
+                f32x4 t[3][NF];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const size_t so = (size_t)(sp + u < nsplit ? sp + u : nsplit - 1) * SPLIT_STRIDE;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) t[u][f] = ld(all + so + f * 64);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[f >> 2][f & 3] += (sp + u < nsplit ? t[u][f] : (f32x4){0.f, 0.f, 0.f, 0.f});
+            }
+            if (lane == 0) g.coop_counter[bid * 4 + wave] = 0;            // ready for the next launch (stream order: nobody else touches it now)
+        }
+    }
+    epilogue_rows<EPI, WMF, 2, FOLD>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane, pre, FOLD ? cb : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1815,6 +1940,21 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
 // CU (>= 256 workgroups) with >= 4 k-steps each, and at least 2 below 512 tiles.  Measured (tools/small_gemm_bench.py,
 // SWEEP=1): text 15.5 us unsplit -> 11.7 at 2 = 11.7 at 4; image (324 tiles) 30.7 -> 24.7 at 2, 26.7 at 4 -- beyond one
 // workgroup per CU more partials only add traffic for the consumer (ln_bwd_add reads every partial).
+// Cooperative split-K of an epilogue-carrying GEMM (GemmArgs::coop_scratch): worth it when a handful of 64-row tiles walk a long K each -- every tile
+// stages its slices at the ~80 GB/s one CU pulls, whatever the other 200 CUs do.  The largest factor of {2, 4} (GRIP_COOP_SPLIT: developer A/B, 1 = off)
+// that leaves every split >= 4 slices and the launch <= 256 workgroups.
+int gemm_pick_coop_split(int M, int N, int K) {
+    static const int force = getenv("GRIP_COOP_SPLIT") ? atoi(getenv("GRIP_COOP_SPLIT")) : 0;
+    const int64_t tiles = ((int64_t)((M + 63) / 64) * (N / BN) + 7) / 8 * 8;
+    const int nk = K / BK;
+    if (N % BN || K % BK || nk < 16 || tiles > 64) return 1;
+    if (force >= 1) return (nk % force == 0 && nk / force >= 3 && tiles * force <= 256) ? force : 1;
+    int best = 1;
+    for (int f : {2, 4})
+        if (nk % f == 0 && nk / f >= 4 && tiles * f <= 256) best = f;
+    return best;
+}
+
 int gemm_pick_ksplit(int M, int N, int K) {
     static const int force = getenv("GRIP_GEMM_KSPLIT") ? atoi(getenv("GRIP_GEMM_KSPLIT")) : 0;   // developer A/B: 1 disables, n forces
     const int64_t tiles = (int64_t)((M + 63) / 64) * (N / BN);
@@ -1972,7 +2112,14 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
         }
     }
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
-    if (ksplit > 1) {
+    const bool coop = ksplit > 1 && (epi == EPI_BIAS_RESID || epi == EPI_BIAS_RESID_STATS);
+    if (coop) {     // cooperative split-K: loader-wave kernel on 64-row tiles only (GemmArgs::coop_scratch)
+        const int64_t t64 = (int64_t)((a.M + 63) / 64) * (a.N / BN);
+        GRIP_REQUIRE(a.coop_scratch && a.coop_counter && (a.K / BK) % ksplit == 0 && (a.K / BK) / ksplit >= 3 && ((t64 + 7) / 8 * 8) * ksplit <= 256,
+                     "gemm: cooperative split-K needs the scratch and counter buffers, (K/64) %% ksplit == 0 with >= 3 slices per split and <= 256 workgroups (M=%d N=%d K=%d ksplit=%d)",
+                     a.M, a.N, a.K, ksplit);
+        variant = 4;
+    } else if (ksplit > 1) {
         GRIP_REQUIRE(epi == EPI_F32 && (a.K / BK) % ksplit == 0 && a.split_stride >= (int64_t)a.M * a.ldc,
                      "gemm: split-K needs EPI_F32, (K/64) %% ksplit == 0 and a partial stride >= M*ldc (K=%d ksplit=%d)", a.K, ksplit);
         // 128-row tiles where gemm_pick_ksplit sized the split for them (more 64-row tiles than CUs: about two 128-row workgroups per CU)
@@ -1982,6 +2129,19 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     }
     if (variant == 5 && epi == EPI_BIAS_RESID_STATS) variant = 6;   // the one-tile-per-workgroup 64-wide kernel has no registers left for the statistics
     *chosen = variant;
+    // At most one workgroup per CU: the ring with the feed on its own waves (gemm_ringw_kernel).  GRIP_GEMM_WSPEC=0: developer A/B.
+    static const bool wspec = !(getenv("GRIP_GEMM_WSPEC") && atoi(getenv("GRIP_GEMM_WSPEC")) == 0);
+    {
+        const int64_t wgs = (int64_t)((a.M + (variant == 4 ? 63 : 127)) / (variant == 4 ? 64 : 128)) * (a.N / BN) * ksplit;
+        const int nk = a.K / BK / ksplit;
+        const bool ringw = wspec && wgs <= 256 && ((variant == 4 && nk >= 3) || (variant == 1 && nk >= 2));
+        if (a.stat_parts > 0 && !ringw) {      // only the loader-wave kernels read the partial sums themselves: finalise them the ordinary way
+            GRIP_REQUIRE(a.stat_in && a.rowstat, "gemm: stat_parts without stat_in / a rowstat buffer to finalise into");
+            const int rc = launch_ln_stats_finalize(a.stat_in, a.stat_parts, const_cast<float*>(a.rowstat), a.M, a.K, s);
+            if (rc) return rc;
+            a.stat_parts = 0;
+        }
+    }
     if (variant == 2) {
         GRIP_REQUIRE(can_big && a.N % 256 == 0, "gemm: 256x256 tile needs N %% 256 == 0 and A padded to 256 rows");
         return launch_big<256, 256, 4>(epi, a, s);
@@ -2014,14 +2174,18 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     const int bmt = variant == 4 ? 64 : 128;
     const int tiles_m = (a.M + bmt - 1) / bmt, tiles_n = a.N / BN;
     dim3 grid(tiles_m * tiles_n, ksplit), block(256);
-    // At most one workgroup per CU: the ring with the feed on its own waves (gemm_ringw_kernel).  GRIP_GEMM_WSPEC=0: developer A/B.
-    static const bool wspec = !(getenv("GRIP_GEMM_WSPEC") && atoi(getenv("GRIP_GEMM_WSPEC")) == 0);
+    if (coop) {
+        GRIP_REQUIRE(wspec, "gemm: cooperative split-K needs the loader-wave kernels (GRIP_GEMM_WSPEC=0 is set)");
+        grid.x = (grid.x + 7) / 8 * 8;       // the splits of a tile on one XCD (gemm_ringw_kernel)
+        return launch_ringw<2, 4>(epi, a, grid, s);
+    }
     if (wspec && (int64_t)grid.x * ksplit <= 256) {
         const int nk = a.K / BK / ksplit;
         if (variant == 4 && nk >= 3) return launch_ringw<2, 4>(epi, a, grid, s);
         if (variant == 1 && nk > 12) return launch_ringw<4, 5>(epi, a, grid, s);
         if (variant == 1 && nk >= 2) return launch_ringw<4, 3>(epi, a, grid, s);
     }
+
     if (variant == 4) {
         // ring depth by workgroups per CU: <= 1 -> four stages (96 KiB), <= 2 -> three (72 KiB, two per CU); beyond that three
         // co-resident two-stage workgroups already keep three tiles in flight per CU

@@ -28,8 +28,11 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
 // One workgroup (4 waves) per image row: the row is normalised and pre-multiplied by the scale in every wave's registers, wave w
 // takes the classes j = w (mod 4) in groups of four (independent row loads and wave reductions in flight), the logits meet in
 // LDS, and wave 0 does the softmax / arg-max tail.  (Round 1 gave a whole row to ONE wave: 102 dependent class trips = 85 us
-// for a 16-row training batch, on the critical path between the text tower's forward and backward.)
-__global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restrict__ img, const float* __restrict__ txtn, float scale,
+// for a 16-row training batch, on the critical path between the text tower's forward and backward.)  NW = waves per row: 4 for pools (many rows fill
+// the chip), 16 for training batches (a few rows: 102 classes are then 2 trips of 4 per wave instead of 7 -- 25.9 us -> r04).  A class's logit is
+// computed by one wave in the same order whatever NW is: the two forms return the same bits.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void cosine_head_kernel(const float* __restrict__ img, const float* __restrict__ txtn, float scale,
                                                           int n, int c, int e, float* __restrict__ logits, float* __restrict__ probs,
                                                           int32_t* __restrict__ am_logits, int32_t* __restrict__ am_probs) {
     __shared__ float lgs[64 * HEAD_MAX_CV];
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void cosine_head_kernel(const float* __restric
     for (int i = 0; i < HEAD_MAX_EV; ++i)
         if (lane + 64 * i < e4) v[i] = scale * (v[i] / nrm);
 
-    for (int j0 = wave * 4; j0 < c; j0 += 16) {
+    for (int j0 = wave * 4; j0 < c; j0 += NW * 4) {
         float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -122,7 +125,10 @@ extern "C" int grip_cosine_head(const float* img_emb, const float* txt_emb, floa
     GRIP_REQUIRE(n > 0 && c > 0 && c <= 64 * HEAD_MAX_CV && e % 4 == 0 && e <= 256 * HEAD_MAX_EV, "cosine_head: unsupported shape n=%d c=%d e=%d", n, c, e);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((c + 3) / 4), dim3(256), 0, s, txt_emb, txt_norm_scratch, c, e);
-    hipLaunchKernelGGL(cosine_head_kernel, dim3(n), dim3(256), 0, s, img_emb, txt_norm_scratch, scale, n, c, e, logits, probs, argmax_logits, argmax_probs);
+    if (n <= 64 && e <= 1024)
+        hipLaunchKernelGGL(cosine_head_kernel<16>, dim3(n), dim3(1024), 0, s, img_emb, txt_norm_scratch, scale, n, c, e, logits, probs, argmax_logits, argmax_probs);
+    else
+        hipLaunchKernelGGL(cosine_head_kernel<4>, dim3(n), dim3(256), 0, s, img_emb, txt_norm_scratch, scale, n, c, e, logits, probs, argmax_logits, argmax_probs);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

@@ -17,14 +17,41 @@ __device__ __forceinline__ f32x4 load4b(const half_t* p, int i) {
     return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 
+// Every global load of the row (x, the dy partials, gamma) is issued before the first reduction: the four wave reductions then run on registers
+// and the row costs ONE memory round trip (r04: with the dy loads behind the statistics the CoOp step's 24 ln_bwd_add launches took 8.7 us each).
 template <int NV, typename XT>
 __device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x4* __restrict__ dyr, const f32x4* __restrict__ gamma,
                                            int lane, int d4, int d, f32x4 (&dx)[NV], int parts = 1, size_t part_stride4 = 0) {
-    f32x4 x[NV];
+    f32x4 x[NV], gm[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            x[i] = load4b(xr, lane + 64 * i);
+            dx[i] = dyr[lane + 64 * i];
+            gm[i] = gamma[lane + 64 * i];
+        }
+    // split-K partials, added in index order, FOUR in flight at a time (the text tower's dgrad GEMMs split eight ways: as a one-load-per-trip loop
+    // the 24 ln_bwd_add launches of a CoOp step spent 8.4 us each waiting for seven dependent trips); slots past the last partial re-read it and add zero
+    for (int p = 1; p < parts; p += 4) {
+        f32x4 t[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t pp = (size_t)(p + u < parts ? p + u : parts - 1) * part_stride4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (lane + 64 * i < d4) t[u][i] = dyr[pp + lane + 64 * i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (lane + 64 * i < d4) dx[i] += (p + u < parts ? t[u][i] : (f32x4){0.f, 0.f, 0.f, 0.f});
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < d4) { x[i] = load4b(xr, lane + 64 * i); s += x[i][0] + x[i][1] + x[i][2] + x[i][3]; }
+        if (lane + 64 * i < d4) s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
     const float mean = wave_sum_b(s) / (float)d;
     float q = 0.f;
 #pragma unroll
@@ -36,9 +63,7 @@ __device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
             x[i] = x[i] * rstd;                                    // xhat
-            f32x4 dy = dyr[lane + 64 * i];
-            for (int p = 1; p < parts; ++p) dy += dyr[p * part_stride4 + lane + 64 * i];   // split-K partials, fixed order
-            dx[i] = dy * gamma[lane + 64 * i];                     // g
+            dx[i] = dx[i] * gm[i];                                 // g
             a += dx[i][0] + dx[i][1] + dx[i][2] + dx[i][3];
             b += dx[i][0] * x[i][0] + dx[i][1] * x[i][1] + dx[i][2] * x[i][2] + dx[i][3] * x[i][3];
         }
@@ -57,14 +82,17 @@ __global__ __launch_bounds__(256) void ln_bwd_add_kernel(const resid_t* __restri
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int d4 = d >> 2;
-    f32x4 g[NV];
-    ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g, parts, part_stride4);
+    f32x4 g[NV], old[NV];
     f32x4* o = (f32x4*)(dx + (size_t)row * d);
     half4* oh = (half4*)(dxh + (size_t)row * d);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) old[i] = o[lane + 64 * i];         // in flight with the row's other loads
+    ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g, parts, part_stride4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
-            const f32x4 v = o[lane + 64 * i] + g[i];
+            const f32x4 v = old[i] + g[i];
             o[lane + 64 * i] = v;
             oh[lane + 64 * i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         }
@@ -193,16 +221,31 @@ __global__ __launch_bounds__(256) void text_prefix_grad_kernel(const float* __re
 // Dynamic loss scale: scale[0] = 2^k with amax(g) * 2^k in [32, 64), scale[1] = 2^-k; g16 = f16(g * scale).
 // Keeps the f16 gradient operands of the dgrad GEMMs away from the subnormal range; the chain is
 // linear in g, so the power-of-two scale is exact and is divided out at the prompt slice.
+// Up to 64 Ki elements (every prompt step: classes x embed_dim or batch x embed_dim) stay in registers between the two passes, all 16 loads of a
+// thread in flight at once (r04; as two loops over memory the single workgroup spent 9.3 us on 13 dependent trips).
 __global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __restrict__ g, half_t* __restrict__ g16, float* __restrict__ scale, int n) {
     __shared__ float red[16];
     __shared__ float sc;
+    constexpr int RC = 16;
     float m = 0.f;
     const int n4 = (n & 3) == 0 ? n >> 2 : 0;        // 16-byte path when the length allows (embedding blocks always do)
-    for (int i = threadIdx.x; i < n4; i += 1024) {
-        const f32x4 v = ((const f32x4*)g)[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    const bool cached = n4 > 0 && n4 <= 1024 * RC;
+    f32x4 v[RC];
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            const int i = threadIdx.x + u * 1024;
+            v[u] = i < n4 ? ((const f32x4*)g)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < RC; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+    } else {
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const f32x4 w = ((const f32x4*)g)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
+        }
+        for (int i = n4 * 4 + threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
     }
-    for (int i = n4 * 4 + threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -222,9 +265,18 @@ __global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __re
     }
     __syncthreads();
     const float s = sc;
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            const int i = threadIdx.x + u * 1024;
+            const f32x4 w = v[u] * s;
+            if (i < n4) ((half4*)g16)[i] = (half4){(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3]};
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n4; i += 1024) {
-        const f32x4 v = ((const f32x4*)g)[i] * s;
-        ((half4*)g16)[i] = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        const f32x4 w = ((const f32x4*)g)[i] * s;
+        ((half4*)g16)[i] = (half4){(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3]};
     }
     for (int i = n4 * 4 + threadIdx.x; i < n; i += 1024) g16[i] = (half_t)(g[i] * s);
 }

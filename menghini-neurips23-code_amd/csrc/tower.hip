@@ -199,6 +199,11 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     int Ps = 0;
     int rs = 0;                // rows between consecutive sequences for the (sequence, position) -> row gathers: S, or S - Ps
     float* kv_part = nullptr;  // [batch, Ps, 2, d] f32: per-class shares of the shared keys' dK / dV (train)
+    // cooperative split-K of the train-mode c_proj GEMM (text tower; GemmArgs::coop_scratch): factor, partial tiles, (tile, wave) tickets
+    int coop_ks = 1;
+    float* coop_scratch = nullptr;
+    int* coop_cnt = nullptr;
+    size_t coop_cnt_bytes = 0;
     half_t* dxh = nullptr;
     half_t* dh = nullptr;
     half_t* dqkv = nullptr;
@@ -240,6 +245,12 @@ struct grip_tower {
 static bool last_block_full() {
     static const bool full = getenv("GRIP_LAST_BLOCK_FULL") && atoi(getenv("GRIP_LAST_BLOCK_FULL")) != 0;
     return full;
+}
+
+// Train-mode forwards of the text tower run LayerNorm-folded GEMMs (run_blocks).
+static bool train_fold(const grip_tower* t) {
+    static const bool on = !(getenv("GRIP_TRAIN_FOLD") && atoi(getenv("GRIP_TRAIN_FOLD")) == 0);
+    return on && t->D.kind == 1 && !t->f32;
 }
 
 static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w, int seq_len = 0, int shared = 0) {
@@ -318,6 +329,15 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
         w.gemb16 = (half_t*)take(Bp * D.embed_dim * 2);
         w.scale = (float*)take(256);
         if (w.Ps) w.kv_part = (float*)take((size_t)batch * w.Ps * 2 * d * 4);
+        if (train_fold(t)) {      // (text tower, f16)
+            w.coop_ks = gemm_pick_coop_split((int)w.M, d, 4 * d);
+            if (w.coop_ks > 1) {
+                const size_t tiles = (size_t)((w.M + 63) / 64) * (size_t)(d / 128);
+                w.coop_scratch = (float*)take(tiles * (size_t)w.coop_ks * 4 * 2048 * sizeof(float));
+                w.coop_cnt_bytes = tiles * 4 * sizeof(int);
+                w.coop_cnt = (int*)take(w.coop_cnt_bytes);
+            }
+        }
     }
     w.bytes = off;
     return GRIP_OK;
@@ -413,13 +433,18 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
     // stream is L2-resident and a LayerNorm launch costs ~5 us, while the statistics-carrying epilogues make the 20-us GEMMs of
     // those steps 5 % slower (r02: VPT step 3.8 -> 4.0 ms with the fold).  The switch is the MODE, never the batch size: every
     // inference call computes a row the same way whatever chunk it arrives in (sharded / re-chunked encodes stay bit-identical).
-    const bool fold = !f && !w.train;
+    // r04: the TEXT tower's train-mode forward folds as well.  Its prompt steps run a few hundred rows (425 for 102 classes x 21 positions with a shared
+    // context): every kernel there is a launch, not a byte count -- 24 LayerNorm launches of 4.7 us in a 1.5-ms step -- and its GEMMs run on the loader-wave
+    // kernels, whose consumer waves add the producer's partial row sums themselves (GemmArgs::stat_in), so no finalising launch replaces them.  The backward is
+    // unchanged: it differentiates LayerNorm from the saved stream rows (ln_bwd_add).  GRIP_TRAIN_FOLD=0: developer A/B.
+    const bool fold = !f && (!w.train || train_fold(t));
+    const bool parts_in = fold && w.train;     // consumers read stat_part directly
     // Last block at inference: only ONE row per sequence of the final stream is ever read (CLS: ln_post(x[:, 0]),
     // models/clip_encoders.py:189; EOT: :86-89), and past the block's attention rows do not mix.  So the block computes K and V for
     // every row but its attention output, out-proj, LayerNorm and MLP for that row alone (M = batch instead of batch x S):
     // 2.2 of the block's 2.9 GFLOP per ViT-B/16 image are never issued, the embedding is unchanged.  GRIP_LAST_BLOCK_FULL=1
     // computes the whole block as the reference does (A/B; the tests hold the two paths equal).
-    const bool rows_only = fold && !last_block_full() && !w.Ps;
+    const bool rows_only = fold && !w.train && !last_block_full() && !w.Ps;
     *compact = false;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
@@ -493,6 +518,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             else RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s, w.Ps));
         } else {
             a.A = x; a.W = t->w16 + lw.in_wG; a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_bb; a.colsum = F + lw.in_cs; a.rowstat = w.rowstat;
+            if (parts_in && l > 0) { a.stat_in = w.stat_part; a.stat_parts = parts; }      // (block 0: the embedding kernel wrote rowstat)
             a.out = qkv; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_LNFOLD_F16, a, s));
             RUN(launch_attention_fwd(qkv, att, w.batch, w.S, H, causal, s, w.Ps));
@@ -508,7 +534,8 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, gf, w.M, d, s));
             a.f32 = gf; a.A = w.xn; a.W = t->wop(t->split ? lw.fc_wS : lw.fc_w); a.bias = F + lw.fc_b;
         } else {
-            RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
+            if (parts_in) { a.stat_in = w.stat_part; a.stat_parts = parts; }
+            else RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
             a.A = x_mid; a.W = t->w16 + lw.fc_wG; a.bias = F + lw.fc_bb; a.colsum = F + lw.fc_cs; a.rowstat = w.rowstat;
         }
         a.M = w.M; a.m_pad = w.Mp; a.N = 4 * d; a.K = d; a.out = w.h; a.ldc = 4 * d;
@@ -518,8 +545,9 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         a.rot_rows = w.train;
         a.f32 = gf; a.A = w.h; a.W = t->wop(t->split ? lw.proj_wS : lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
         a.stat_part = (!fold || last) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
+        if (w.train && w.coop_ks > 1) { a.ksplit = w.coop_ks; a.coop_scratch = w.coop_scratch; a.coop_counter = w.coop_cnt; }
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
-        if (fold && !last) RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
+        if (fold && !last && !parts_in) RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
         x = x_out;
     }
     *x_final = x;
@@ -602,7 +630,8 @@ extern "C" int grip_text_forward(grip_tower* t, const int32_t* token_ids, const 
         const int d = D.width, f = t->f32;
         const float* F = t->w32;
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, train ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s, w.Ps));
+        if (train && w.coop_cnt) GRIP_CHECK_HIP(hipMemsetAsync(w.coop_cnt, 0, w.coop_cnt_bytes, s));     // the tickets start at zero (and return to it)
+        RUN(launch_text_embed(token_ids, D.seq0, F + t->L.tok, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, prefix_classes, x0, f, (train && !train_fold(t)) ? nullptr : w.rowstat, n_class, w.S, d, D.vocab, s, w.Ps));
         resid_t* xf = nullptr;
         bool compact = false;
         RUN(run_blocks(t, w, x0, /*causal=*/1, eot_index, s, &xf, &compact));
@@ -649,6 +678,20 @@ extern "C" int grip_debug_gemm_ln(int epi, const void* A, const void* W, int M, 
     a.stat_part = stat_part; a.rowstat = rowstat; a.colsum = colsum;
     return launch_gemm(epi, a, (hipStream_t)stream);
 }
+// The two prompt-step forms of r04 (csrc/gemm.hip).  epi 7 / 8 with stat_in != NULL: the consumer adds the producer's stat_parts partial pairs itself
+// (loader-wave kernels) or the launcher finalises them into `rowstat` (must be writable) first.  epi 3 with ksplit > 1: cooperative split-K, partial
+// tiles through coop_scratch (>= tiles * ksplit * 32 KiB), tickets in coop_counter (tiles * 4 ints, zero on entry, zero again on exit).
+extern "C" int grip_debug_gemm_train(int epi, const void* A, const void* W, int M, int N, int K, const float* bias, const void* resid, void* out, void* out2,
+                                     float* stat_part, float* rowstat, const float* colsum, const float* stat_in, int stat_parts, int ksplit,
+                                     float* coop_scratch, int* coop_counter, int m_pad, void* stream) {
+    GemmArgs a{};
+    a.rot_rows = 1;
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid; a.out = out; a.out2 = out2; a.ldc = N;
+    a.stat_part = stat_part; a.rowstat = rowstat; a.colsum = colsum; a.stat_in = stat_in; a.stat_parts = stat_parts;
+    a.ksplit = ksplit; a.coop_scratch = coop_scratch; a.coop_counter = coop_counter;
+    return launch_gemm(epi, a, (hipStream_t)stream);
+}
+extern "C" int grip_debug_coop_split(int M, int N, int K) { return gemm_pick_coop_split(M, N, K); }
 extern "C" int grip_debug_ln_fold(const void* W, const float* gamma, const float* beta, const float* bias, void* Wg, float* colsum, float* bias_out,
                                   int N, int K, const float* stat_part, int parts, float* rowstat, int M, int d, void* stream) {
     int rc = launch_ln_fold_weights((const half_t*)W, gamma, beta, bias, (half_t*)Wg, colsum, bias_out, N, K, (hipStream_t)stream);

@@ -86,6 +86,9 @@ _DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of
     "grip_debug_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "grip_debug_gemm_ln": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_void_p]),
+    "grip_debug_gemm_train": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "grip_debug_coop_split": (c_int, [c_int, c_int, c_int]),
     "grip_debug_gemm_splitk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p]),
     "grip_debug_ln_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                    c_int, c_int, c_void_p]),

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_posemb.py tests/test_gpu_errors.py -q -m gpu > gpurun_out/t_posemb.log 2>&1; tail -n 5 gpurun_out/t_posemb.log
+timeout 2400 python -m pytest tests/test_gpu_trainfold.py tests/test_gpu_backward.py tests/test_gpu_trajectory.py -q -m gpu -x > gpurun_out/t_all.log 2>&1; tail -n 12 gpurun_out/t_all.log
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/st_coop
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_coop -o r -- python $GRAFT_REPO_ROOT/tools/coop_feature_loop.py 30 > /dev/null 2>&1
