@@ -271,6 +271,9 @@ int launch_ln_bwd_init(const resid_t* x, const float* dln, int parts, int64_t pa
                        float* dx, half_t* dxh, int M, int d, hipStream_t s);
 int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
                           int n, int d, hipStream_t s);
+// ... with the zero fill of every other row of dx / dxh [M, d] folded in (sequences start at row `first`)
+int launch_ln_bwd_scatter_fill(const resid_t* x, const float* dy, const int32_t* index, int stride, int first, const float* gamma, float* dx, half_t* dxh,
+                               int n, int M, int d, hipStream_t s);
 int launch_vit_prefix_grad(const float* dx, const float* prefix, const float* gamma, const float* scale, float* grad, int B, int S, int P, int d, hipStream_t s);
 int launch_text_prefix_grad(const float* dx, const float* scale, float* grad, int C, int T, int P, int prefix_classes, int d, hipStream_t s);
 int launch_grad_scale_cast(const float* g, half_t* g16, float* scale, int n, hipStream_t s);

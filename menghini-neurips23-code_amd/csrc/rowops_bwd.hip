@@ -149,6 +149,33 @@ __global__ __launch_bounds__(256) void ln_bwd_scatter_kernel(const resid_t* __re
         }
 }
 
+// The same with the zero fill folded in (r04: two memset nodes and this kernel were three launches of a prompt step): every row r < M of dx / dxh is
+// written -- LNbwd(dy[b]; x[r]) where r is the read row of its sequence b (r = b * stride + index[b], sequences start at row `first`: 0, or Ps in the
+// shared-prefix layout whose leading rows belong to no sequence's read position), zero elsewhere.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_scatter_fill_kernel(const resid_t* __restrict__ x, const float* __restrict__ dy, const int32_t* __restrict__ index,
+                                                                  int stride, int first, const float* __restrict__ gamma, float* __restrict__ dx,
+                                                                  half_t* __restrict__ dxh, int n, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int d4 = d >> 2;
+    const int b = row >= first ? (row - first) / stride : -1;
+    const bool read = b >= 0 && b < n && row == b * stride + (index ? index[b] : 0);
+    f32x4 g[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) g[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (read) ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dy + (size_t)b * d), (const f32x4*)gamma, lane, d4, d, g);
+    f32x4* o = (f32x4*)(dx + (size_t)row * d);
+    half4* oh = (half4*)(dxh + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            o[lane + 64 * i] = g[i];
+            oh[lane + 64 * i] = (half4){(half_t)g[i][0], (half_t)g[i][1], (half_t)g[i][2], (half_t)g[i][3]};
+        }
+}
+
 // Visual prompt slice through ln_pre: grad_prefix[s] = inv_scale * sum_b LNbwd(dx[b*S + 1 + s]; prefix[s]).
 // One workgroup of 8 waves per prompt token: wave w sums the images b = w (mod 8) in order, the eight partial rows meet in LDS and wave 0
 // adds them in wave order (deterministic).  (Until r03 one wave walked the whole batch: 16 dependent LayerNorm-backward rows = 32 us.)
@@ -312,6 +339,13 @@ int launch_ln_bwd_init(const resid_t* x, const float* dln, int parts, int64_t pa
 int launch_ln_bwd_scatter(const resid_t* x, const float* dy, const int32_t* index, int stride, const float* gamma, float* dx, half_t* dxh,
                           int n, int d, hipStream_t s) {
     DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_scatter_kernel<NV>, dim3((n + 3) / 4), dim3(256), 0, s, x, dy, index, stride, gamma, dx, dxh, n, d));
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+int launch_ln_bwd_scatter_fill(const resid_t* x, const float* dy, const int32_t* index, int stride, int first, const float* gamma, float* dx, half_t* dxh,
+                               int n, int M, int d, hipStream_t s) {
+    GRIP_REQUIRE(stride >= 1 && first >= 0, "ln_bwd_scatter_fill: bad layout (stride=%d first=%d)", stride, first);
+    DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_scatter_fill_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, dy, index, stride, first, gamma, dx, dxh, n, M, d));
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

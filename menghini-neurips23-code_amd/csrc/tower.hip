@@ -329,7 +329,7 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
         w.gemb16 = (half_t*)take(Bp * D.embed_dim * 2);
         w.scale = (float*)take(256);
         if (w.Ps) w.kv_part = (float*)take((size_t)batch * w.Ps * 2 * d * 4);
-        if (train_fold(t)) {      // (text tower, f16)
+        if (D.kind == 1 && !t->f32) {      // text tower, f16
             w.coop_ks = gemm_pick_coop_split((int)w.M, d, 4 * d);
             if (w.coop_ks > 1) {
                 const size_t tiles = (size_t)((w.M + 63) / 64) * (size_t)(d / 128);
@@ -801,10 +801,9 @@ static int backward_head_of_tower(grip_tower* t, Workspace& w, const float* grad
     RUN(launch_gemm(EPI_F32, a, s));
     if (w.rows_last)      // compact: the final stream exists for the read rows only (run_blocks)
         return launch_ln_bwd_scatter(w.row_xout, w.dcls, nullptr, 1, t->w32 + t->L.lnpost_g, w.drow, w.drow_h, w.batch, d, s);
-    GRIP_CHECK_HIP(hipMemsetAsync(w.dx, 0, (size_t)w.M * d * 4, s));
-    GRIP_CHECK_HIP(hipMemsetAsync(w.dxh, 0, (size_t)w.M * d * 2, s));
-    // row of (sequence b, position index[b]): b * rs + index[b] in either layout (shared-prefix: Ps + b*(S-Ps) + index - Ps)
-    RUN(launch_ln_bwd_scatter(w.x_in[(size_t)D.layers], w.dcls, index, w.rs, t->w32 + t->L.lnpost_g, w.dx, w.dxh, w.batch, d, s));
+    // row of (sequence b, position index[b]): b * rs + index[b] in either layout (shared-prefix: Ps + b*(S-Ps) + index - Ps); every other row of the
+    // stream gradient starts at zero (written by the same kernel)
+    RUN(launch_ln_bwd_scatter_fill(w.x_in[(size_t)D.layers], w.dcls, index, w.rs, w.Ps, t->w32 + t->L.lnpost_g, w.dx, w.dxh, w.batch, (int)w.M, d, s));
     return GRIP_OK;
 }
 
