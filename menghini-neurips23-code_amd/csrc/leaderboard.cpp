@@ -12,7 +12,9 @@
 // binary insertion once a board is sorted.  O(n*c) compares, no allocation inside the scan.
 // The path strings are represented by their rank among all paths (dense, equal strings share a
 // rank), computed by the host layer with Python's own string order.
+#include <math.h>
 #include <sched.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -207,6 +209,7 @@ struct Prefilter {
         std::unique_ptr<float[]> own;              //     cache miss per row otherwise); own[r] = the row's own-class probability
         std::unique_ptr<int32_t[]> n_cand, n_spill;
         std::vector<double> t_snap;             // T_lo per class when the block was requested
+        std::vector<float> t_snap_f;            // ... and floats at or below them (the workers' screen)
     } buf[2];
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -215,10 +218,30 @@ struct Prefilter {
     bool quit = false;
     int nthreads = 0;
 
+    // Floats that bound a double from below / above with room for the float arithmetic of the screen (two roundings of 2^-24 against a margin of 1e-6)
+    static float f_below(double t) {
+        if (t < -3e38) return -INFINITY;
+        if (!(t == t)) return t > 0 ? 0.f : -INFINITY;    // (NaN: never produced by the scan; screen everything in)
+        float f = (float)(t - std::fabs(t) * 1e-6 - 1e-37);
+        if ((double)f > t) f = std::nextafterf(f, -INFINITY);
+        return f;
+    }
+    static float f_above(double t) {
+        float f = (float)(t + std::fabs(t) * 1e-6 + 1e-37);
+        if ((double)f < t) f = std::nextafterf(f, INFINITY);
+        return f;
+    }
+    // Two passes per row: a branch-free float SCREEN over all c classes (auto-vectorised; a superset of both tests by construction of f_below /
+    // f_above), then the exact double tests of the sequential scan on the few survivors -- the lists that come out are the ones the one-pass double
+    // loop produced (r04: that loop, 102 convert-multiply-compare-branch steps per row, was what the scan thread waited for at N = 400 000).
     void work(const Buf& b_, int part, int parts) {
         Buf& b = const_cast<Buf&>(b_);
         const int64_t rows = b.hi - b.lo;
         const int64_t r0 = b.lo + rows * part / parts, r1 = b.lo + rows * (part + 1) / parts;
+        const int c8 = (c + 7) & ~7;
+        std::vector<uint8_t> flags((size_t)c8 + 8, 0);
+        uint8_t* fl = flags.data();
+        const float* tf = b.t_snap_f.data();
         for (int64_t i = r0; i < r1; ++i) {
             const float* p = probs + i * c;
             const int js = pred[i];
@@ -230,12 +253,23 @@ struct Prefilter {
             float* cdp = b.cand_p.get() + (i - b.lo) * c;
             float* spp = b.spill_p.get() + (i - b.lo) * c;
             b.own[(size_t)(i - b.lo)] = (js >= 0 && js < c) ? p[js] : 0.f;
-            int nc = 0, ns = 0;
+            const float uf = f_above(up), sf = slack != 0.0 ? f_above(slack) : 0.f;
+            const float xl = eps != 0.f ? f_below(xlo) : INFINITY;     // eps == 0: no arg-max candidates at all
             for (int j = 0; j < c; ++j) {
-                if (j == js) continue;
-                const double hi = (double)p[j] * up + slack;
-                if (eps != 0.f && hi >= xlo) { cd[nc] = (uint16_t)j; cdp[nc++] = p[j]; }
-                if (!(hi < b.t_snap[(size_t)j])) { sp[ns] = (uint16_t)j; spp[ns++] = p[j]; }
+                const float h = p[j] * uf + sf;
+                fl[j] = (uint8_t)((!(h < xl) ? 1 : 0) | (!(h < tf[j]) ? 2 : 0) | (p[j] < 0.f ? 3 : 0));     // (a negative input: the float bounds assume p >= 0)
+            }
+            int nc = 0, ns = 0;
+            for (int j8 = 0; j8 < c8; j8 += 8) {
+                uint64_t w;
+                memcpy(&w, fl + j8, 8);
+                if (!w) continue;
+                for (int j = j8; j < j8 + 8 && j < c; ++j) {
+                    if (!fl[j] || j == js) continue;
+                    const double hi = (double)p[j] * up + slack;
+                    if (eps != 0.f && hi >= xlo) { cd[nc] = (uint16_t)j; cdp[nc++] = p[j]; }
+                    if (!(hi < b.t_snap[(size_t)j])) { sp[ns] = (uint16_t)j; spp[ns++] = p[j]; }
+                }
             }
             b.n_cand[(size_t)(i - b.lo)] = nc;
             b.n_spill[(size_t)(i - b.lo)] = ns;
@@ -274,6 +308,8 @@ struct Prefilter {
         Buf& b = buf[w];
         b.lo = lo; b.hi = std::min(n, lo + BLOCK);
         b.t_snap = t_lo;
+        b.t_snap_f.resize(t_lo.size());
+        for (size_t j = 0; j < t_lo.size(); ++j) b.t_snap_f[j] = f_below(t_lo[j]);
         {
             std::lock_guard<std::mutex> lk(mu);
             which = w; pending = nthreads - 1; ++gen;

@@ -337,3 +337,31 @@ def test_parallel_prefilter_changes_nothing(monkeypatch, dominant, k):
         want = cbind.leaderboard_ref(p32, a32, paths, list(range(c)), k)
         got, st = _refine(p32, a32, p16, a16, paths, k)
         assert got == want
+
+
+def test_parallel_prefilter_float_screen_edge_values(monkeypatch):
+    """The workers screen a row's classes in float before the exact double tests (csrc/leaderboard.cpp, Prefilter::work): values the float bounds are not made
+    for -- NaN, +inf, negative, subnormal, zero rows -- and a class count that is not a multiple of the 8-flag scan word must come out as in the
+    single-threaded scan, whose loop has no screen."""
+    import grip_amd  # noqa: F401
+    from grip_amd import engine, pseudolabels as pl
+    n, c = 40000, 37
+    p32, a32, p16, a16, paths = _pool(n, c, 0.25, 2e-3, 77, dominant=True)
+    p16 = p16.copy()
+    r = np.random.RandomState(3)
+    rows = r.choice(n, 400, replace=False)
+    for q, i in enumerate(rows):
+        j = int(r.randint(c))
+        if j == a16[i]:
+            continue
+        p16[i, j] = [np.nan, np.inf, -1e-3, 1e-42, 0.0, -0.0, np.float32(p16[i, a16[i]])][q % 7]
+    ranks = pl.path_ranks(paths)
+    rel = np.full(n, 2e-2, np.float32)
+    rel[::5] = 0
+    rel[1::11] = 0.9
+    out = {}
+    for threads in ("1", "5"):
+        monkeypatch.setenv("GRIP_SCAN_THREADS", threads)
+        out[threads] = engine.leaderboard_scan_bounded(p16, a16, ranks, rel, 7, 1e-30)
+    for a, b in zip(out["1"], out["5"]):
+        assert np.array_equal(a, b)
