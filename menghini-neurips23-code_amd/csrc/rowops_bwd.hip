@@ -17,6 +17,22 @@ __device__ __forceinline__ f32x4 load4b(const half_t* p, int i) {
     return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 
+// dx += the NU partial rows at dp, dp + stride, ...: all loads first, then the adds in index order (straight-line code per NU)
+template <int NU, int NV>
+__device__ __forceinline__ void add_parts(const f32x4* __restrict__ dp, size_t stride4, int lane, int d4, f32x4 (&dx)[NV]) {
+    f32x4 t[NU][NV];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < d4) t[u][i] = dp[(size_t)u * stride4 + lane + 64 * i];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < d4) dx[i] += t[u][i];
+}
+
 // Every global load of the row (x, the dy partials, gamma) is issued before the first reduction: the four wave reductions then run on registers
 // and the row costs ONE memory round trip (r04: with the dy loads behind the statistics the CoOp step's 24 ln_bwd_add launches took 8.7 us each).
 template <int NV, typename XT>
@@ -30,22 +46,16 @@ __device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x
             dx[i] = dyr[lane + 64 * i];
             gm[i] = gamma[lane + 64 * i];
         }
-    // split-K partials, added in index order, FOUR in flight at a time (the text tower's dgrad GEMMs split eight ways: as a one-load-per-trip loop
-    // the 24 ln_bwd_add launches of a CoOp step spent 8.4 us each waiting for seven dependent trips); slots past the last partial re-read it and add zero
+    // split-K partials, added in index order, up to FOUR in flight at a time (the text tower's dgrad GEMMs split eight ways: as a one-load-per-trip loop
+    // the 24 ln_bwd_add launches of a CoOp step spent 8.4 us each waiting for seven dependent trips).  The guards are wave-uniform branches: a slot past
+    // the last partial loads nothing (re-reading the last partial instead cost the image tower's bandwidth-bound launches 2 us: 3 partials -> 5 reads).
     for (int p = 1; p < parts; p += 4) {
-        f32x4 t[4][NV];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t pp = (size_t)(p + u < parts ? p + u : parts - 1) * part_stride4;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (lane + 64 * i < d4) t[u][i] = dyr[pp + lane + 64 * i];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (lane + 64 * i < d4) dx[i] += (p + u < parts ? t[u][i] : (f32x4){0.f, 0.f, 0.f, 0.f});
+        const f32x4* dp = dyr + (size_t)p * part_stride4;
+        switch (parts - p < 4 ? parts - p : 4) {
+            case 1: add_parts<1, NV>(dp, part_stride4, lane, d4, dx); break;
+            case 2: add_parts<2, NV>(dp, part_stride4, lane, d4, dx); break;
+            case 3: add_parts<3, NV>(dp, part_stride4, lane, d4, dx); break;
+            default: add_parts<4, NV>(dp, part_stride4, lane, d4, dx); break;
         }
     }
     float s = 0.f;
@@ -74,8 +84,44 @@ __device__ __forceinline__ void ln_bwd_row(const XT* __restrict__ xr, const f32x
         if (lane + 64 * i < d4) dx[i] = (dx[i] - a - x[i] * b) * rstd;
 }
 
+// The same row with the loads where they are used (the form until r04): fewer registers in flight, more waves per CU -- what the bandwidth-bound
+// launches want (image tower, M = 3 408 rows x 768, three partials: 63 MB per launch; 11.5 us this way, 13.0 with everything in flight).  Same
+// arithmetic in the same order: the two forms return the same bits.
+template <int NV, typename XT>
+__device__ __forceinline__ void ln_bwd_row_stream(const XT* __restrict__ xr, const f32x4* __restrict__ dyr, const f32x4* __restrict__ gamma,
+                                                  int lane, int d4, int d, f32x4 (&dx)[NV], int parts, size_t part_stride4) {
+    f32x4 x[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) { x[i] = load4b(xr, lane + 64 * i); s += x[i][0] + x[i][1] + x[i][2] + x[i][3]; }
+    const float mean = wave_sum_b(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) { x[i] = x[i] - mean; q += x[i][0] * x[i][0] + x[i][1] * x[i][1] + x[i][2] * x[i][2] + x[i][3] * x[i][3]; }
+    const float rstd = rsqrtf(wave_sum_b(q) / (float)d + LN_EPS);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) {
+            x[i] = x[i] * rstd;                                    // xhat
+            f32x4 dy = dyr[lane + 64 * i];
+            for (int p = 1; p < parts; ++p) dy += dyr[p * part_stride4 + lane + 64 * i];   // split-K partials, fixed order
+            dx[i] = dy * gamma[lane + 64 * i];                     // g
+            a += dx[i][0] + dx[i][1] + dx[i][2] + dx[i][3];
+            b += dx[i][0] * x[i][0] + dx[i][1] * x[i][1] + dx[i][2] * x[i][2] + dx[i][3] * x[i][3];
+        }
+    a = wave_sum_b(a) / (float)d;
+    b = wave_sum_b(b) / (float)d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < d4) dx[i] = (dx[i] - a - x[i] * b) * rstd;
+}
+
 // dx[r] += LNbwd(sum_p dln[p][r]; x[r]);  dxh[r] = f16(dx[r])            (r < M; p over the split-K partials of the producer)
-template <int NV>
+// EARLY: every load of the row in flight before the first reduction (few rows: latency-bound); otherwise the streaming form above.
+template <int NV, bool EARLY>
 __global__ __launch_bounds__(256) void ln_bwd_add_kernel(const resid_t* __restrict__ x, const float* __restrict__ dln, const float* __restrict__ gamma,
                                                          float* __restrict__ dx, half_t* __restrict__ dxh, int M, int d, int parts, size_t part_stride4) {
     const int lane = threadIdx.x & 63;
@@ -85,10 +131,17 @@ __global__ __launch_bounds__(256) void ln_bwd_add_kernel(const resid_t* __restri
     f32x4 g[NV], old[NV];
     f32x4* o = (f32x4*)(dx + (size_t)row * d);
     half4* oh = (half4*)(dxh + (size_t)row * d);
+    if constexpr (EARLY) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-        if (lane + 64 * i < d4) old[i] = o[lane + 64 * i];         // in flight with the row's other loads
-    ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g, parts, part_stride4);
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < d4) old[i] = o[lane + 64 * i];         // in flight with the row's other loads
+        ln_bwd_row<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g, parts, part_stride4);
+    } else {
+        ln_bwd_row_stream<NV>(x + (size_t)row * d, (const f32x4*)(dln + (size_t)row * d), (const f32x4*)gamma, lane, d4, d, g, parts, part_stride4);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < d4) old[i] = o[lane + 64 * i];
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < d4) {
@@ -324,7 +377,11 @@ __global__ __launch_bounds__(1024) void grad_scale_cast_kernel(const float* __re
 
 int launch_ln_bwd_add(const resid_t* x, const float* dln, int parts, int64_t part_stride, const float* gamma, float* dx, half_t* dxh, int M, int d, hipStream_t s) {
     GRIP_REQUIRE(parts >= 1 && part_stride % 4 == 0, "ln_bwd_add: bad partial layout (parts=%d stride=%lld)", parts, (long long)part_stride);
-    DISPATCH_NV_B(d, hipLaunchKernelGGL(ln_bwd_add_kernel<NV>, dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, dx, dxh, M, d, parts, (size_t)(part_stride / 4)));
+    if (M <= 1024) {     // a few hundred rows (text tower): latency-bound, every load in flight at once; else the streaming form
+        DISPATCH_NV_B(d, hipLaunchKernelGGL((ln_bwd_add_kernel<NV, true>), dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, dx, dxh, M, d, parts, (size_t)(part_stride / 4)));
+    } else {
+        DISPATCH_NV_B(d, hipLaunchKernelGGL((ln_bwd_add_kernel<NV, false>), dim3((M + 3) / 4), dim3(256), 0, s, x, dln, gamma, dx, dxh, M, d, parts, (size_t)(part_stride / 4)));
+    }
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
