@@ -1945,6 +1945,8 @@ static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
 // that leaves every split >= 4 slices and the launch <= 256 workgroups.
 int gemm_pick_coop_split(int M, int N, int K) {
     static const int force = getenv("GRIP_COOP_SPLIT") ? atoi(getenv("GRIP_COOP_SPLIT")) : 0;
+    static const bool wspec = !(getenv("GRIP_GEMM_WSPEC") && atoi(getenv("GRIP_GEMM_WSPEC")) == 0);
+    if (!wspec) return 1;                          // the form lives in the loader-wave kernel only
     const int64_t tiles = ((int64_t)((M + 63) / 64) * (N / BN) + 7) / 8 * 8;
     const int nk = K / BK;
     if (N % BN || K % BK || nk < 16 || tiles > 64) return 1;
