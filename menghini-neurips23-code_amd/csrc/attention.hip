@@ -49,8 +49,12 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
     if (GRIP_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
     // The launcher guarantees (KVC-1)*32 < S <= KVC*32: every tile before the last 32-key chunk is full, so
     // only the last two tiles (and causal rows) pay for the mask; the code stays one straight-line block.
+    // The LAST 16-key tile holds no key at all when S <= (2 KVC - 1) * 16 (S = 197: keys 208 .. 223): its scores would all be masked to -inf and its
+    // probabilities exact zeros, so neither its two score MFMAs nor its four exponentials are issued (r04; a wave-uniform branch; same bits).
+    const bool last_dead = S <= (2 * KVC - 1) * 16;
 #pragma unroll
     for (int t = 0; t < 2 * KVC; ++t) {
+        if (t == 2 * KVC - 1 && last_dead) { sc[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -73,9 +77,11 @@ __device__ __forceinline__ void attn_tile(const half_t* Ks, const half_t* Vt, ha
     const float m2 = m * LOG2E;
     if (GRIP_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int t = 0; t < 2 * KVC; ++t)
+    for (int t = 0; t < 2 * KVC; ++t) {
+        if (t == 2 * KVC - 1 && last_dead) { sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; continue; }       // exp(-inf - m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][r], LOG2E, -m2));   // exp(s - m)
+    }
     if (GRIP_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(0);
 
     // The row sums come out of the matrix pipe: a fifth accumulator takes an all-ones A operand, so every row of it is
