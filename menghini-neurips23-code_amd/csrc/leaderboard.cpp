@@ -605,11 +605,24 @@ extern "C" int grip_leaderboard_scan_bounded(const float* probs, const int32_t* 
         BoundedScan s{probs, pred, path_rank, rel_eps, n, c, std::min<int64_t>(k, std::max<int64_t>(n, 1)), false, (double)abs_eps};
         const char* env = getenv("GRIP_SCAN_STRICT");       // developer A/B: certify every comparison of the literal algorithm
         s.strict = env && env[0] == '1';
-        {   // threads of the parallel pre-filter: $GRIP_SCAN_THREADS, else the CPUs this process may use (at most 16); small problems run on one
+        {   // threads of the parallel pre-filter: $GRIP_SCAN_THREADS, else the CPUs this process may use -- affinity mask, capped by the cgroup CPU quota
+            // (the MI355X boxes show 256 logical CPUs under a 16-CPU quota), divided among the ranks of the node ($LOCAL_WORLD_SIZE: every rank runs the
+            // replicated scan at the same moment) -- at most 16; small problems run on one
             const char* te = getenv("GRIP_SCAN_THREADS");
             int t = te ? atoi(te) : (int)std::thread::hardware_concurrency();
-            cpu_set_t set;
-            if (!te && sched_getaffinity(0, sizeof(set), &set) == 0) t = std::min(t, CPU_COUNT(&set));
+            if (!te) {
+                cpu_set_t set;
+                if (sched_getaffinity(0, sizeof(set), &set) == 0) t = std::min(t, CPU_COUNT(&set));
+                if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                    char quota[32] = {0};
+                    long period = 0;
+                    if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+                        t = std::min<long>(t, std::max<long>(1, atol(quota) / period));
+                    fclose(f);
+                }
+                const char* lw = getenv("LOCAL_WORLD_SIZE");
+                if (lw && atoi(lw) > 1) t = std::max(1, t / atoi(lw));
+            }
             s.threads = std::max(1, std::min(t, 16));
             if ((int64_t)n * c < (int64_t)4 << 20) s.threads = 1;
         }
