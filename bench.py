@@ -161,7 +161,7 @@ class Loop:
                     mine = torch.from_numpy(idx[(idx >= lo) & (idx < lo + a.pool)] - lo).to(self.device)
                     emb_rows = torch.empty(len(mine), self.d.embed_dim, dtype=torch.float32, device=self.device)
                     if len(mine):
-                        tower.encode_chunks(lambda s, e: self.pool[mine[s:e]], emb_rows, 0, len(mine), chunk, streams=1)
+                        tower.encode_chunks(lambda s, e: self.pool[mine[s:e]], emb_rows, 0, len(mine), chunk, streams=pl.tier_streams())
                     emb_rows = gdist.allgather_selected(emb_rows, idx, self.n_total)
                     _, p, _, ap = engine.cosine_head(emb_rows, txt, scale)
                     out = p.cpu().numpy(), ap.cpu().numpy()

@@ -7,6 +7,8 @@ Two algorithmic changes against the reference loop (utils/clip_pseudolabels.py:3
 which changes a result: the class prompts are encoded once instead of once per image, and images
 go through the tower in chunks instead of one by one.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -328,6 +330,12 @@ def mode():
 SPLIT_TIER_MIN_ROWS = 4096      # pools below this go straight from the f16 screen to the f32 tower (the split twin costs HBM and a build)
 
 
+def tier_streams():
+    """HIP streams the re-encodes of a refinement tier alternate their chunks on ($GRIP_TIER_STREAMS, default 2 as for the pool encode: the split tower's
+    bandwidth-bound kernels of one chunk run next to the GEMMs of the other, refine_split 0.81 -> 0.79 s per two passes; rows do not depend on it)."""
+    return 1 if os.environ.get("GRIP_TIER_STREAMS", "2") == "1" else 2
+
+
 def mid_tower(clip_model, n_rows):
     """The vision tower of `clip_model`'s split-f16 twin when the middle tier pays for a pool of `n_rows` rows, else None.
     $GRIP_SPLIT_TIER: "auto" (default: pools of >= SPLIT_TIER_MIN_ROWS rows), "1" always, "0" never."""
@@ -378,7 +386,7 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
             mine = idx[(idx >= lo) & (idx < hi)]
             local = torch.empty(len(mine), tower.embed_dim, dtype=torch.float32, device=dev)
             if len(mine):
-                tower.encode_chunks(lambda a, b: take_images(images, mine[a:b]), local, 0, len(mine), tier_chunk, prefix, streams=1)
+                tower.encode_chunks(lambda a, b: take_images(images, mine[a:b]), local, 0, len(mine), tier_chunk, prefix, streams=tier_streams())
             encoded[tier] += len(mine)
             got = gdist.allgather_selected(local, idx, n)
             _, p, al, ap = engine.cosine_head(got, txt_exact, scale)
