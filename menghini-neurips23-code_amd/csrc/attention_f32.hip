@@ -105,3 +105,85 @@ int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, 
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ONE query row per sequence (the last block of an inference forward of the f32 / split-f16 towers: only the CLS / EOT row of the final stream is
+// ever read, csrc/tower.hip run_blocks): out[b] = softmax(q_b K_b^T / 8) V_b per head, all f32 on the vector ALUs.  One wave per (sequence, head):
+// lanes over keys for the scores (64 fused multiply-adds per key, accurate expf as in the kernel above), then lane = (key group, 8-wide slice of the
+// head dim) for P.V with a fixed fold of the eight key groups.  qrows [B, D] f32 = the projected query rows; qkv [B * S, 3 D] f32 holds K and V.
+template <bool SPLIT>
+__global__ __launch_bounds__(64) void attn_row_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ qrows, const int32_t* __restrict__ row_index,
+                                                          float* __restrict__ out, int S, int H, int causal) {
+    extern __shared__ float sm_row[];     // [64] q, [S] probabilities
+    float* qs = sm_row;
+    float* ps = sm_row + 64;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * 64;
+    const size_t ld = (size_t)3 * D;
+    const int r = row_index ? row_index[b] : 0;
+    const float* base = qkv + (size_t)b * S * ld + h * 64;
+    qs[lane] = qrows[(size_t)b * D + h * 64 + lane] * 0.125f;       // 1/sqrt(64), exact
+    __syncthreads();
+    const int n_keys = causal ? r + 1 : S;
+    float m = -INFINITY;
+    for (int j = lane; j < n_keys; j += 64) {
+        const f32x4* kr = (const f32x4*)(base + (size_t)j * ld + D);
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 kv = kr[c];
+            a = fmaf(qs[c * 4 + 0], kv[0], a); a = fmaf(qs[c * 4 + 1], kv[1], a); a = fmaf(qs[c * 4 + 2], kv[2], a); a = fmaf(qs[c * 4 + 3], kv[3], a);
+        }
+        ps[j] = a;
+        m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int j = lane; j < n_keys; j += 64) {
+        const float p = expf(ps[j] - m);
+        ps[j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int kg = lane >> 3, ch = lane & 7;          // key group, 8-wide slice of the head dim
+    for (int j = kg; j < n_keys; j += 8) {
+        const f32x4* vr = (const f32x4*)(base + (size_t)j * ld + 2 * D + ch * 8);
+        const f32x4 v0 = vr[0], v1 = vr[1];
+        const float p = ps[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[0][e] = fmaf(p, v0[e], acc[0][e]); acc[1][e] = fmaf(p, v1[e], acc[1][e]); }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[u][e] += __shfl_xor(acc[u][e], 8);
+            acc[u][e] += __shfl_xor(acc[u][e], 16);
+            acc[u][e] += __shfl_xor(acc[u][e], 32);
+        }
+    if (kg == 0) {
+        const f32x4 o0 = acc[0] / sum, o1 = acc[1] / sum;
+        if constexpr (SPLIT) {
+            const SplitRow row{(half_t*)out + (size_t)b * 2 * D};
+            store4(row, h * 16 + ch * 2, o0);
+            store4(row, h * 16 + ch * 2 + 1, o1);
+        } else {
+            f32x4* op = (f32x4*)(out + (size_t)b * D + h * 64 + ch * 8);
+            op[0] = o0;
+            op[1] = o1;
+        }
+    }
+}
+
+int launch_attention_row_f32(const float* qkv, const float* qrows, const int32_t* row_index, float* out, int B, int S, int H, int causal, hipStream_t s, int split_out) {
+    GRIP_REQUIRE(S >= 1 && B >= 1 && H >= 1 && qrows, "attention_row_f32: bad arguments B=%d S=%d H=%d", B, S, H);
+    const size_t lds = (size_t)(64 + S) * sizeof(float);
+    if (split_out) hipLaunchKernelGGL(attn_row_f32_kernel<true>, dim3(B * H), dim3(64), lds, s, qkv, qrows, row_index, out, S, H, causal);
+    else hipLaunchKernelGGL(attn_row_f32_kernel<false>, dim3(B * H), dim3(64), lds, s, qkv, qrows, row_index, out, S, H, causal);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}

@@ -256,6 +256,10 @@ int launch_attention_row_bwd(const half_t* qkv, const half_t* o_rows, const half
                              hipStream_t s);
 // split_out != 0: `out` is written in the split layout of gemm_split.hip (it feeds the out-proj GEMM of a precision-2 tower)
 int launch_attention_fwd_f32(const float* qkv, float* out, int B, int S, int H, int causal, hipStream_t s, int split_out = 0);
+// one query row per sequence (qrows [B, H*64] f32: the projected rows), K / V from the packed f32 qkv; out [B, H*64] f32 or, split_out != 0, the split layout
+int launch_attention_row_f32(const float* qkv, const float* qrows, const int32_t* row_index, float* out, int B, int S, int H, int causal, hipStream_t s, int split_out = 0);
+// rows of 4-byte elements (f32, or the split-f16 layout): out[b] = x[b * row_stride + (row_index ? row_index[b] : 0)]
+int launch_gather_rows4(const void* x, const int32_t* row_index, int row_stride, void* out, int n_rows, int d, hipStream_t s);
 // precision-2 towers, S <= 320 (attention_split.hip): f32 qkv in, both products as three f16 MFMAs on hi / lo' operand pairs, split-layout out
 bool attention_split_supported(int S);
 int launch_attention_fwd_split(const float* qkv, void* out, int B, int S, int H, int causal, hipStream_t s);

@@ -352,6 +352,22 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const half_t* __restri
     ((half8*)out)[(size_t)b * d8 + c] = ((const half8*)x)[src * d8 + c];
 }
 
+// the same for rows of 4-byte elements (f32 values, or the split-f16 layout, whose row pitch is an f32 row's)
+__global__ __launch_bounds__(256) void gather_rows4_kernel(const f32x4* __restrict__ x, const int32_t* __restrict__ row_index, int row_stride,
+                                                           f32x4* __restrict__ out, int n_rows, int d4) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_rows * d4) return;
+    const int b = idx / d4, c = idx - b * d4;
+    const size_t src = (size_t)b * row_stride + (row_index ? row_index[b] : 0);
+    out[(size_t)b * d4 + c] = x[src * d4 + c];
+}
+int launch_gather_rows4(const void* x, const int32_t* row_index, int row_stride, void* out, int n_rows, int d, hipStream_t s) {
+    GRIP_REQUIRE(d % 4 == 0, "gather_rows4: width %% 4 != 0");
+    hipLaunchKernelGGL(gather_rows4_kernel, dim3((n_rows * (d / 4) + 255) / 256), dim3(256), 0, s, (const f32x4*)x, row_index, row_stride, (f32x4*)out, n_rows, d / 4);
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
 int launch_gather_rows(const half_t* x, const int32_t* row_index, int row_stride, half_t* out, int n_rows, int d, hipStream_t s) {
     GRIP_REQUIRE(d % 8 == 0, "gather_rows: width %% 8 != 0");
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n_rows * (d / 8) + 255) / 256), dim3(256), 0, s, x, row_index, row_stride, out, n_rows, d / 8);

@@ -278,11 +278,11 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     w.h = (half_t*)take(w.Mp * 4 * d * es);
     w.cls16 = (half_t*)take(Bp * d * es);
     w.rows_last = train && !t->f32 && !shared && !last_block_full();
-    if (!t->f32 && (!train || w.rows_last)) {
-        w.row_x = (half_t*)take(Bp * d * 2);
-        w.row_att = (half_t*)take(Bp * d * 2);
-        w.row_xn = (half_t*)take(Bp * d * 2);
-        w.row_h = (half_t*)take(Bp * 4 * d * 2);
+    if (!train || w.rows_last) {       // compact [batch, .] buffers of a last block that runs for the read rows only (f32 / split towers: 4-byte elements)
+        w.row_x = (half_t*)take(Bp * d * es);
+        w.row_att = (half_t*)take(Bp * d * es);
+        w.row_xn = (half_t*)take(Bp * d * es);
+        w.row_h = (half_t*)take(Bp * 4 * d * es);
     }
     if (w.rows_last) {
         w.row_hpre = (half_t*)take(Bp * 4 * d * 2);
@@ -471,6 +471,39 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
             a = GemmArgs{};
             a.A = w.row_h; a.W = t->w16 + lw.proj_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_RESID, a, s));
+            x = w.row_x;
+            *compact = true;
+            break;
+        }
+        if (last && f && !w.train && !last_block_full() && !w.Ps) {
+            // The same for the f32 / split-f16 towers (r04: the refinement tiers and the exact mode computed the whole 12th block -- 6 % of their FLOPs -- for
+            // one row per image): ln_1 and the K / V projection for every row, then the read rows alone: Q, a one-row f32 attention, out-proj, ln_2, MLP.
+            const int64_t Bp = round_up64(w.batch, 256);
+            const size_t wb = (size_t)d * d * 4;                      // bytes of d weight rows (f32 elements, or the split layout: the same row pitch)
+            const char* in_w = (const char*)t->wop(t->split ? lw.in_wS : lw.in_w);
+            float* qkv32 = (float*)(void*)w.qkv;
+            GemmArgs a{};
+            RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, gf, w.M, d, s));
+            a.f32 = gf; a.A = w.xn; a.W = in_w + wb; a.M = w.M; a.m_pad = w.Mp; a.N = 2 * d; a.K = d; a.bias = F + lw.in_b + d; a.out = qkv32 + d; a.ldc = 3 * d;
+            RUN(launch_gemm(EPI_BIAS_F16, a, s));
+            RUN(launch_gather_rows4(x, read_rows, w.S, w.row_x, w.batch, d, s));
+            RUN(launch_gather_rows4(w.xn, read_rows, w.S, w.row_xn, w.batch, d, s));
+            a = GemmArgs{};
+            a.f32 = gf; a.A = w.row_xn; a.W = in_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.in_b; a.out = w.row_h; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_F16, a, s));
+            RUN(launch_attention_row_f32(qkv32, (const float*)(const void*)w.row_h, read_rows, (float*)(void*)w.row_att, w.batch, w.S, H, causal, s, t->split));
+            a = GemmArgs{};
+            a.f32 = gf; a.A = w.row_att; a.W = t->wop(t->split ? lw.out_wS : lw.out_w); a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.out_b;
+            a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
+            RUN(launch_gemm(EPI_BIAS_RESID, a, s));
+            RUN(launch_layernorm_f16(w.row_x, F + lw.ln2_g, F + lw.ln2_b, w.row_xn, gf, w.batch, d, s));
+            a = GemmArgs{};
+            a.f32 = gf; a.A = w.row_xn; a.W = t->wop(t->split ? lw.fc_wS : lw.fc_w); a.M = w.batch; a.m_pad = Bp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.row_h; a.ldc = 4 * d;
+            RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
+            a = GemmArgs{};
+            a.f32 = gf; a.A = w.row_h; a.W = t->wop(t->split ? lw.proj_wS : lw.proj_w); a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b;
+            a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
             RUN(launch_gemm(EPI_BIAS_RESID, a, s));
             x = w.row_x;
             *compact = true;
