@@ -431,8 +431,11 @@ def exact_block(loop, lib):
     dt_h = time.perf_counter() - t0
     a.mode = mode
     pe, ph = set(zip(img_e.tolist(), cls_e.tolist())), set(zip(img_h.tolist(), cls_h.tolist()))
+    f_exec = F_IMG if os.environ.get("GRIP_LAST_BLOCK_FULL", "0") not in ("", "0") else vit_flops_executed()
     return {"exact_images_per_sec": loop.n_total / dt, "pool_images": loop.n_total, "dtype": "f32",
-            "achieved_tflops": loop.n_total * F_IMG / dt / 1e12, "peak_tflops": PEAK_F32_TFLOPS, "frac": loop.n_total * F_IMG / dt / 1e12 / PEAK_F32_TFLOPS,
+            # (executed FLOPs: since r04 the f32 tower's last block runs for the CLS row only, like the f16 tower's)
+            "achieved_tflops": loop.n_total * f_exec / dt / 1e12, "algorithmic_tflops": loop.n_total * F_IMG / dt / 1e12, "peak_tflops": PEAK_F32_TFLOPS,
+            "frac": loop.n_total * f_exec / dt / 1e12 / PEAK_F32_TFLOPS,
             "pairs_exact": len(pe),
             "timed_loop_lists_identical_to_exact": bool(np.array_equal(img_l, img_e) and np.array_equal(cls_l, cls_e)),
             "timed_loop_mode": mode,
@@ -754,7 +757,7 @@ def main():
     peak = PEAK_F32_TFLOPS if dom < 16 else PEAK_F16_TFLOPS       # profiler variant 0 = the exact tower's f32 GEMM
     rs = loop.refine_stats
     if rs is not None:      # the rows the identical pass re-encoded with the f32 tower are work the engine issued on top of the algorithmic count
-        executed += args.steps * rs["rows_refined"] * F_IMG       # (the f32 tower computes the whole last block)
+        executed += args.steps * (rs.get("rows_mid", 0) + rs.get("rows_exact", rs["rows_refined"])) * f_img_x       # (every re-encode of either tier; rows-only last block since r04)
     out = {
         "metric": "images/sec CLIP ViT-B/16 encode+prompt-step",
         "value": images / elapsed,
@@ -811,7 +814,8 @@ def main():
         "flops_note": "per GPU; algorithmic = BASELINE.md section 2 (35.13 GF per image, 77 text positions per prompt); executed = what the engine "
                       f"issues: {f_img_x / 1e9:.2f} GF per frozen image forward (the last block's Q / attention / out-proj / MLP only for the CLS row: no other "
                       f"row of its output is read) and the text tower's {seq_zs} (zero-shot) / {seq} (CoOp) encoded positions (positions after the last "
-                      "EOT cannot influence any output); results are identical either way",
+                      "EOT cannot influence any output), plus every row the refinement tiers re-encode (counted once per re-encode at the same GF; the split-f16 "
+                      "tier issues three f16 MFMA products per multiply-add: not counted); results are identical either way",
         "roofline": {
             "bound": "mfma", "kernel": kname(dom), "kernel_instantiation": full_kernel_name(dom),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
