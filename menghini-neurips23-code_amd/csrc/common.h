@@ -185,9 +185,8 @@ struct GemmArgs {
     float* stat_part;      // EPI_BIAS_RESID, optional: [N/64, M, 2] per-row partial (sum, sum of squares) of the values written, one pair
                            // per 64-column wave tile; ln_stats_finalize turns them into rowstat for the consuming GEMM
     const float* rowstat;  // EPI_LNFOLD_*: [M, 2] (mean, rstd) of A's rows
-    const float* stat_in;  // EPI_LNFOLD_*, optional: the producer's stat_part array ([stat_parts, M, 2]) when nobody has finalised it yet.  The loader-wave
-    int stat_parts;        // kernels (gemm_ringw_kernel) add the pairs themselves -- same order and arithmetic as ln_stats_finalize -- so a prompt step pays
-                           // no launch for it; for any other kernel the launcher runs ln_stats_finalize into `rowstat` (which must then be writable) first
+    const float* stat_in;  // EPI_LNFOLD_*, optional: the producer's stat_part array ([stat_parts, M, 2]) when nobody has finalised it yet: every kernel adds the
+    int stat_parts;        // pairs itself (gemm.hip, row_stat: same order and arithmetic as ln_stats_finalize), so a prompt step pays no launch for it
     const float* colsum;   // EPI_LNFOLD_*: [N]
     // Split-K (EPI_F32 on the small-M kernels only): ksplit > 1 launches ksplit workgroups per output tile, each contracting
     // K/ksplit and writing its partial product to out + split * split_stride (floats); the consumer sums the partials

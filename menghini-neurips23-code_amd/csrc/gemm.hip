@@ -88,6 +88,23 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 #define EPI_LDW 68   // slab row stride in floats: conflict-free ds_write_b128, <= 2-way ds_read_b128
 #define EPI_SLAB_FLOATS (32 * EPI_LDW)
 
+// (mean, rstd) of row r of A for the LayerNorm-folded epilogues: the finalised pair, or -- GemmArgs::stat_in -- the sum of the producer's stat_parts partial
+// (sum, sum of squares) pairs in index order with ln_stats_finalize's arithmetic (train-mode forwards: no finalising launch between the GEMMs).
+__device__ __forceinline__ float2 row_stat(const GemmArgs& g, int r) {
+    if (g.stat_parts <= 0) return ((const float2*)g.rowstat)[r];
+    const float2* sp = (const float2*)g.stat_in + r;
+    float sm = 0.f, sq = 0.f;
+    for (int i = 0; i < g.stat_parts; ++i) {
+        const float2 v = sp[(size_t)i * g.M];
+        sm += v.x;
+        sq += v.y;
+    }
+    const float inv_d = 1.0f / (float)g.K;
+    const float mean = sm * inv_d;
+    const float var = fmaxf(sq * inv_d - mean * mean, 0.f);
+    return make_float2(mean, rsqrtf(var + 1e-5f));
+}
+
 // Accumulators start at the bias (epilogues with one) instead of zero: a lane's acc[i][j] holds columns col0 + j*16 +
 // (lane>>4)*4 .. +3 of some row for every row fragment i, so four float4 loads at kernel entry replace one v_add per output
 // element in the epilogue.
@@ -162,7 +179,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
             if constexpr (FOLD && !PRE) {
                 int row = row0 + p * RP + it * 4 + rr;
                 if constexpr (CHECK) row = row < g.M ? row : g.M - 1;
-                rst[b][it] = ((const float2*)g.rowstat)[row];      // the 16 lanes of a row read one address: a broadcast load
+                rst[b][it] = row_stat(g, row);      // the 16 lanes of a row read one address: broadcast loads
             }
         }
     };
@@ -346,7 +363,7 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
                 } else {
                     int rr_ = row;
                     if constexpr (CHECK) rr_ = rr_ < g.M ? rr_ : g.M - 1;
-                    st = ((const float2*)g.rowstat)[rr_];
+                    st = row_stat(g, rr_);
                 }
             }
             if (!CHECK || row < g.M) {
@@ -412,7 +429,7 @@ __device__ __forceinline__ void epilogue_rows8h_impl(const GemmArgs& g, f32x4 (&
         } else {
             int rr_ = row0 + p * 16 + frow;
             rr_ = rr_ < g.M ? rr_ : g.M - 1;
-            st = ((const float2*)g.rowstat)[rr_];
+            st = row_stat(g, rr_);
         }
         half_t* buf = slab + (p & 1) * 1024;
 #pragma unroll
@@ -485,7 +502,7 @@ __device__ __forceinline__ void epilogue_direct_impl(const GemmArgs& g, f32x4 (&
         } else {
             int rr_ = row;
             if constexpr (CHECK) rr_ = rr_ < g.M ? rr_ : g.M - 1;
-            st = ((const float2*)g.rowstat)[rr_];
+            st = row_stat(g, rr_);
         }
         if (!CHECK || row < g.M) {
             f32x4 v[4];
@@ -862,21 +879,7 @@ __global__ __launch_bounds__(512) void gemm_ringw_kernel(GemmArgs g, int tiles_m
         cb[1] = *(const f32x4*)(g.bias + n0 + wc * 64 + (lane & 15) * 4);
         int r = m0 + wr * WMF * 16 + (lane & (WMF * 16 - 1));
         r = r < g.M ? r : g.M - 1;
-        if (g.stat_parts > 0) {
-            const float2* sp = (const float2*)g.stat_in + r;
-            float sm = 0.f, sq = 0.f;
-            for (int i = 0; i < g.stat_parts; ++i) {
-                const float2 v = sp[(size_t)i * g.M];
-                sm += v.x;
-                sq += v.y;
-            }
-            const float inv_d = 1.0f / (float)g.K;
-            const float mean = sm * inv_d;
-            const float var = fmaxf(sq * inv_d - mean * mean, 0.f);
-            pre[0] = make_float2(mean, rsqrtf(var + 1e-5f));
-        } else {
-            pre[0] = ((const float2*)g.rowstat)[r];
-        }
+        pre[0] = row_stat(g, r);
     }
     half8 fa[2][WMF], fb[2][4];
     auto rd = [&](const half_t* st, int kk) {
@@ -1582,7 +1585,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
             for (int h = 0; h < 2; ++h) {
                 int r = m0 + wr * 128 + h * 64 + lane;
                 r = r < g.M ? r : g.M - 1;
-                pre[h] = ((const float2*)g.rowstat)[r];
+                pre[h] = row_stat(g, r);
             }
         }
         load_frags(0, par, 0);
@@ -2133,17 +2136,7 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     *chosen = variant;
     // At most one workgroup per CU: the ring with the feed on its own waves (gemm_ringw_kernel).  GRIP_GEMM_WSPEC=0: developer A/B.
     static const bool wspec = !(getenv("GRIP_GEMM_WSPEC") && atoi(getenv("GRIP_GEMM_WSPEC")) == 0);
-    {
-        const int64_t wgs = (int64_t)((a.M + (variant == 4 ? 63 : 127)) / (variant == 4 ? 64 : 128)) * (a.N / BN) * ksplit;
-        const int nk = a.K / BK / ksplit;
-        const bool ringw = wspec && wgs <= 256 && ((variant == 4 && nk >= 3) || (variant == 1 && nk >= 2));
-        if (a.stat_parts > 0 && !ringw) {      // only the loader-wave kernels read the partial sums themselves: finalise them the ordinary way
-            GRIP_REQUIRE(a.stat_in && a.rowstat, "gemm: stat_parts without stat_in / a rowstat buffer to finalise into");
-            const int rc = launch_ln_stats_finalize(a.stat_in, a.stat_parts, const_cast<float*>(a.rowstat), a.M, a.K, s);
-            if (rc) return rc;
-            a.stat_parts = 0;
-        }
-    }
+    GRIP_REQUIRE(a.stat_parts <= 0 || a.stat_in, "gemm: stat_parts without stat_in");      // (every kernel reads the partial sums itself: row_stat)
     if (variant == 2) {
         GRIP_REQUIRE(can_big && a.N % 256 == 0, "gemm: 256x256 tile needs N %% 256 == 0 and A padded to 256 rows");
         return launch_big<256, 256, 4>(epi, a, s);

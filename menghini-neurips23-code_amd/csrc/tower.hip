@@ -249,8 +249,9 @@ static bool last_block_full() {
 
 // Train-mode forwards of the text tower run LayerNorm-folded GEMMs (run_blocks).
 static bool train_fold(const grip_tower* t) {
-    static const bool on = !(getenv("GRIP_TRAIN_FOLD") && atoi(getenv("GRIP_TRAIN_FOLD")) == 0);
-    return on && t->D.kind == 1 && !t->f32;
+    // GRIP_TRAIN_FOLD: 0 = off, 1 = text tower only (default), 2 = the image tower's prompt steps as well (developer A/B)
+    static const int mode = getenv("GRIP_TRAIN_FOLD") ? atoi(getenv("GRIP_TRAIN_FOLD")) : 1;
+    return !t->f32 && (mode >= 2 || (mode == 1 && t->D.kind == 1));
 }
 
 static int carve(const grip_tower* t, int batch, int P, int train, char* base, Workspace& w, int seq_len = 0, int shared = 0) {
@@ -632,7 +633,7 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         a.f32 = f; a.A = w.patches; a.W = t->wop(t->L.conv_w); a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, train ? nullptr : w.rowstat, batch, G2, d, s));
+        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, (train && !train_fold(t)) ? nullptr : w.rowstat, batch, G2, d, s));
         resid_t* xf = nullptr;
         bool compact = false;
         RUN(run_blocks(t, w, x0, /*causal=*/0, nullptr, s, &xf, &compact));
