@@ -293,6 +293,7 @@ int launch_transpose(const void* in, void* out, int f32, int rows, int cols, int
 //     row-major layout scattered them over 8 lines); one thread per row adds the d/64 pairs in a fixed order and turns them into (mean, rstd).  96 B in, 8 B out per row
 //     at d = 768 -- against 2 x 1 536 B for a stand-alone LayerNorm pass over the stream.
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int parts, float* __restrict__ rowstat, int M, float inv_d) {
+#pragma clang fp contract(off)      // (gemm.hip's row_stat computes the same pair inside the consuming GEMM: identical roundings)
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= M) return;
     const float2* p = (const float2*)part + row;         // [parts][M]: consecutive threads read consecutive pairs

@@ -249,8 +249,8 @@ static bool last_block_full() {
 
 // Train-mode forwards of the text tower run LayerNorm-folded GEMMs (run_blocks).
 static bool train_fold(const grip_tower* t) {
-    // GRIP_TRAIN_FOLD: 0 = off, 1 = text tower only (default), 2 = the image tower's prompt steps as well (developer A/B)
-    static const int mode = getenv("GRIP_TRAIN_FOLD") ? atoi(getenv("GRIP_TRAIN_FOLD")) : 1;
+    // GRIP_TRAIN_FOLD (developer A/B): 0 = off, 1 = text tower only, 2 = both towers (default)
+    static const int mode = getenv("GRIP_TRAIN_FOLD") ? atoi(getenv("GRIP_TRAIN_FOLD")) : 2;
     return !t->f32 && (mode >= 2 || (mode == 1 && t->D.kind == 1));
 }
 
@@ -434,10 +434,12 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
     // stream is L2-resident and a LayerNorm launch costs ~5 us, while the statistics-carrying epilogues make the 20-us GEMMs of
     // those steps 5 % slower (r02: VPT step 3.8 -> 4.0 ms with the fold).  The switch is the MODE, never the batch size: every
     // inference call computes a row the same way whatever chunk it arrives in (sharded / re-chunked encodes stay bit-identical).
-    // r04: the TEXT tower's train-mode forward folds as well.  Its prompt steps run a few hundred rows (425 for 102 classes x 21 positions with a shared
-    // context): every kernel there is a launch, not a byte count -- 24 LayerNorm launches of 4.7 us in a 1.5-ms step -- and its GEMMs run on the loader-wave
-    // kernels, whose consumer waves add the producer's partial row sums themselves (GemmArgs::stat_in), so no finalising launch replaces them.  The backward is
-    // unchanged: it differentiates LayerNorm from the saved stream rows (ln_bwd_add).  GRIP_TRAIN_FOLD=0: developer A/B.
+    // r04: train-mode forwards fold as well, without a finalising launch: the GEMM that consumes a stream adds the producer's partial row sums itself
+    // (GemmArgs::stat_in; gemm.hip row_stat, fetched per ROW before the K loop).  For the text tower's few hundred rows every kernel is a launch, not a byte
+    // count (24 LayerNorm launches of 4.7 us in a 1.5-ms CoOp step); for the image tower's 3 408 rows the folded epilogues cost 1 - 4 us per GEMM against the
+    // 5.5-us LayerNorm they replace (VPT step 2.98 -> 2.95 ms, UPT 3.29 -> 3.24 ms, 22 launches fewer; r02's form -- statistics loaded per row group in the
+    // epilogue plus a finalising launch -- had been 5 % slower).  The backward is unchanged: it differentiates LayerNorm from the saved stream rows.
+    // GRIP_TRAIN_FOLD = 0 / 1 / 2: off / text tower only / both (developer A/B).
     const bool fold = !f && (!w.train || train_fold(t));
     const bool parts_in = fold && w.train;     // consumers read stat_part directly
     // Last block at inference: only ONE row per sequence of the final stream is ever read (CLS: ln_post(x[:, 0]),
