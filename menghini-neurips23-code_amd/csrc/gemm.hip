@@ -1627,7 +1627,7 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
             for (int h = 0; h < 2; ++h) {
                 int r = m0 + wr * 128 + h * 64 + lane;
                 r = r < g.M ? r : g.M - 1;
-                pre[h] = row_stat(g, r);
+                pre[h] = ((const float2*)g.rowstat)[r];      // (finalised pairs only: the launcher finalises partial sums for this kernel -- keeps the hot loop's code as it was)
             }
         }
         load_frags(0, par, 0);
@@ -2178,7 +2178,13 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     *chosen = variant;
     // At most one workgroup per CU: the ring with the feed on its own waves (gemm_ringw_kernel).  GRIP_GEMM_WSPEC=0: developer A/B.
     static const bool wspec = !(getenv("GRIP_GEMM_WSPEC") && atoi(getenv("GRIP_GEMM_WSPEC")) == 0);
-    GRIP_REQUIRE(a.stat_parts <= 0 || a.stat_in, "gemm: stat_parts without stat_in");      // (every kernel reads the partial sums itself: row_stat)
+    GRIP_REQUIRE(a.stat_parts <= 0 || a.stat_in, "gemm: stat_parts without stat_in");      // (every kernel but the persistent one reads the partial sums itself: row_stat)
+    if (a.stat_parts > 0 && variant == 6) {      // the persistent kernel (pool-sized M) takes finalised statistics only
+        GRIP_REQUIRE(a.rowstat, "gemm: partial row sums on the persistent kernel need a rowstat buffer to finalise into");
+        const int rc = launch_ln_stats_finalize(a.stat_in, a.stat_parts, const_cast<float*>(a.rowstat), a.M, a.K, s);
+        if (rc) return rc;
+        a.stat_parts = 0;
+    }
     if (variant == 2) {
         GRIP_REQUIRE(can_big && a.N % 256 == 0, "gemm: 256x256 tile needs N %% 256 == 0 and A padded to 256 rows");
         return launch_big<256, 256, 4>(epi, a, s);
