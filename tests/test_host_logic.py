@@ -279,3 +279,19 @@ def test_grip_schedule_matches_the_reference_formula():
         num_iter, num_samples, want = reference_schedule(n_unlabeled, q, c)
         got = [TrainingStrategy._n_pseudoshots(None, niter, num_samples, n_unlabeled, c) for niter in range(1, num_iter + 1)]
         assert got == want, (n_unlabeled, q, c, got, want)
+
+
+def test_cooperative_split_factor_choice():
+    """Host-side shape logic of the cooperative split-K GEMM (csrc/gemm.hip, gemm_pick_coop_split; no GPU needed): used for a few dozen 64 x 128 tiles walking
+    >= 16 K slices (the text tower's c_proj in a prompt step), never for launches that fill the chip on their own."""
+    import grip_amd  # noqa: F401
+    from grip_amd import native
+    lib = native.lib()
+    f = lib.grip_debug_coop_split
+    assert f(425, 512, 2048) == 4          # CoOp step: 28 tiles x 32 slices -> 4 x 8, 128 workgroups on one XCD each
+    assert f(240, 512, 2048) == 4          # UPT text side
+    assert f(425, 768, 3072) == 4          # ViT-L/14's text tower
+    assert f(2142, 512, 2048) == 1         # plain row layout, 102 x 21 rows: 136 tiles are a launch of their own
+    assert f(425, 512, 512) == 1           # 8 slices: nothing to split
+    assert f(3408, 768, 3072) == 1         # the image tower's prompt step
+    assert f(425, 500, 2048) == 1          # N % 128 != 0
