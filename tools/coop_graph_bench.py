@@ -35,4 +35,4 @@ for rep in range(5):
         g(f, y, w)
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t) / n)
-print(f"graphed CoOp feature step: {best * 1e3:.3f} ms per replay ({B / best:.0f} img/s at B = {B})  env: TRAIN_FOLD={os.environ.get('GRIP_TRAIN_FOLD', '1')} COOP_SPLIT={os.environ.get('GRIP_COOP_SPLIT', 'auto')}")
+print(f"graphed CoOp feature step: {best * 1e3:.3f} ms per replay ({B / best:.0f} img/s at B = {B})  env: TRAIN_FOLD={os.environ.get('GRIP_TRAIN_FOLD', '2')} COOP_SPLIT={os.environ.get('GRIP_COOP_SPLIT', 'auto')}")
