@@ -13,7 +13,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "common.h"
+#include "host_common.h"
 
 namespace {
 struct PairHash {

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "../../include/grip_amd.h"
+#include "host_common.h"
 
 typedef _Float16 half_t;
 typedef half_t half8 __attribute__((ext_vector_type(8)));
@@ -21,8 +21,6 @@ typedef half_t resid_t;
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
 
-void grip_set_error(const char* fmt, ...);
-
 #define GRIP_CHECK_HIP(expr)                                                                   \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -30,14 +28,6 @@ void grip_set_error(const char* fmt, ...);
             grip_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
             return GRIP_ERR_HIP;                                                               \
         }                                                                                      \
-    } while (0)
-
-#define GRIP_REQUIRE(cond, ...)             \
-    do {                                    \
-        if (!(cond)) {                      \
-            grip_set_error(__VA_ARGS__);    \
-            return GRIP_ERR_ARG;            \
-        }                                   \
     } while (0)
 
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

@@ -27,7 +27,7 @@
 #include <thread>
 #include <vector>
 
-#include "common.h"
+#include "host_common.h"
 
 namespace {
 struct Entry {

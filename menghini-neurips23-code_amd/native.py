@@ -10,6 +10,7 @@ from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRIP_LIB") or os.path.join(_HERE, "libgrip_amd.so")      # GRIP_LIB: another build of the same ABI (developer A/B)
+HOST_LIB_PATH = os.environ.get("GRIP_HOST_LIB")       # developer: a sanitizer build of the host-only sources (`make -C csrc sanitize`) whose grip_leaderboard_* / grip_bpe_* replace the library's
 ABI_VERSION = 6
 FWD_TRAIN, FWD_SHARED_PREFIX, FWD_NO_POS_EMB = 1, 2, 4      # grip_text_forward flags
 
@@ -122,6 +123,14 @@ def lib():
             fn.argtypes = args
         if l.grip_abi_version() != ABI_VERSION:
             raise GripError(f"libgrip_amd.so ABI {l.grip_abi_version()} != host layer ABI {ABI_VERSION}; rebuild")
+        if HOST_LIB_PATH:
+            h = ctypes.CDLL(HOST_LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                if name.startswith(("grip_leaderboard_", "grip_bpe_")):
+                    fn = getattr(h, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                    setattr(l, name, fn)
         _lib = l
     return _lib
 

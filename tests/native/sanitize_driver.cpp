@@ -1,0 +1,212 @@
+// Sanitizer driver for the host-only sources of the library (csrc/leaderboard.cpp, csrc/bpe.cpp): built by `make -C
+// menghini-neurips23-code_amd/csrc sanitize` with g++ -fsanitize=thread and -fsanitize=address,undefined and run on the CPU (GPU sanitizers are
+// not available on this pool).  It drives the code paths that hold threads and raw buffers:
+//   * grip_leaderboard_scan_bounded with the worker-thread pre-filter (n * c >= 4 M), several refinement rounds, every result compared with the
+//     single-threaded scan of the same inputs (marks, lists) and, once everything is final, with grip_leaderboard_scan;
+//   * grip_bpe_* on a synthetic merges table: concurrent encodes through one handle (the per-word cache under its mutex), malformed tables,
+//     truncated inputs, output buffers that are too small.
+// The reference has no such code (its scan is a Python loop, utils/clip_pseudolabels.py:49-112; its tokenizer is third-party Python).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/grip_amd.h"
+
+static int fails = 0;
+#define CHECK(c, ...) do { if (!(c)) { ++fails; fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } } while (0)
+
+struct Pool {
+    int64_t n; int c;
+    std::vector<float> exact, screen, eps;
+    std::vector<int32_t> pred_exact, pred;
+    std::vector<int64_t> rank;
+};
+
+static Pool make_pool(int64_t n, int c, double spread, double sigma, unsigned seed, bool dominant) {
+    Pool p; p.n = n; p.c = c;
+    p.exact.resize((size_t)(n * c)); p.screen.resize((size_t)(n * c)); p.eps.assign((size_t)n, (float)(6 * sigma));
+    p.pred_exact.resize((size_t)n); p.pred.resize((size_t)n); p.rank.resize((size_t)n);
+    std::mt19937_64 g(seed);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    std::vector<double> z((size_t)c);
+    for (int64_t i = 0; i < n; ++i) {
+        double m = -1e300, s = 0;
+        for (int j = 0; j < c; ++j) { z[(size_t)j] = nd(g) * spread + (dominant && j == 1 ? 3.0 : 0.0); m = std::max(m, z[(size_t)j]); }
+        for (int j = 0; j < c; ++j) { z[(size_t)j] = exp(z[(size_t)j] - m); s += z[(size_t)j]; }
+        int a = 0, b = 0;
+        for (int j = 0; j < c; ++j) {
+            const float e = (float)(z[(size_t)j] / s);
+            double d = nd(g); d = std::max(-5.0, std::min(5.0, d));
+            const float q = (float)((double)e * (1.0 + d * sigma));
+            p.exact[(size_t)(i * c + j)] = e; p.screen[(size_t)(i * c + j)] = q;
+            if (e > p.exact[(size_t)(i * c + a)]) a = j;
+            if (q > p.screen[(size_t)(i * c + b)]) b = j;
+        }
+        p.pred_exact[(size_t)i] = a; p.pred[(size_t)i] = b;
+        p.rank[(size_t)i] = (i * 7919) % n;          // a permutation when gcd(7919, n) == 1, ties otherwise: both are legal inputs
+    }
+    return p;
+}
+
+struct Result { std::vector<int32_t> img, cls; std::vector<uint8_t> amb; int64_t count = 0, n_amb = 0; int rc = 0; };
+
+static Result bounded(const Pool& p, const std::vector<float>& probs, const std::vector<int32_t>& pred, const std::vector<float>& eps, int64_t k, int threads) {
+    Result r;
+    const int64_t cap = k == 10000000 ? p.n : (int64_t)p.c * std::min<int64_t>(k, p.n);
+    r.img.assign((size_t)cap, -1); r.cls.assign((size_t)cap, -1); r.amb.assign((size_t)p.n, 7);
+    char buf[16]; snprintf(buf, sizeof buf, "%d", threads);
+    setenv("GRIP_SCAN_THREADS", buf, 1);
+    r.rc = grip_leaderboard_scan_bounded(probs.data(), pred.data(), p.rank.data(), eps.data(), 1e-30f, p.n, p.c, k, r.img.data(), r.cls.data(), &r.count,
+                                         r.amb.data(), &r.n_amb);
+    return r;
+}
+
+static void scan_case(const char* name, int64_t n, int c, double spread, double sigma, unsigned seed, bool dominant, int64_t k) {
+    Pool p = make_pool(n, c, spread, sigma, seed, dominant);
+    std::vector<float> probs = p.screen, eps = p.eps;
+    std::vector<int32_t> pred = p.pred;
+    int rounds = 0;
+    int64_t refined = 0;
+    for (;; ++rounds) {
+        Result a = bounded(p, probs, pred, eps, k, 1), b = bounded(p, probs, pred, eps, k, 8);
+        CHECK(a.rc == 0 && b.rc == 0, "%s: rc %d / %d", name, a.rc, b.rc);
+        CHECK(a.count == b.count && a.n_amb == b.n_amb && a.img == b.img && a.cls == b.cls && a.amb == b.amb,
+              "%s round %d: the threaded pre-filter changed the scan (count %lld/%lld, marked %lld/%lld)", name, rounds,
+              (long long)a.count, (long long)b.count, (long long)a.n_amb, (long long)b.n_amb);
+        if (b.n_amb == 0) {
+            // certified: the lists must be the plain scan's over the TRUE probabilities (the screen obeys its bound by construction)
+            if (k != 10000000) {
+                Result e; e.img.assign((size_t)(p.c * std::min<int64_t>(k, p.n)), -1); e.cls = e.img;
+                e.rc = grip_leaderboard_scan(p.exact.data(), p.pred_exact.data(), p.rank.data(), p.n, p.c, k, e.img.data(), e.cls.data(), &e.count);
+                CHECK(e.rc == 0 && e.count == b.count, "%s: plain scan count %lld vs %lld", name, (long long)e.count, (long long)b.count);
+                e.img.resize((size_t)e.count); e.cls.resize((size_t)e.count);
+                std::vector<int32_t> bi(b.img.begin(), b.img.begin() + b.count), bc(b.cls.begin(), b.cls.begin() + b.count);
+                CHECK(e.img == bi && e.cls == bc, "%s: certified lists differ from the exact scan's", name);
+            }
+            break;
+        }
+        for (int64_t i = 0; i < p.n; ++i)
+            if (b.amb[(size_t)i]) {
+                CHECK(eps[(size_t)i] != 0.f, "%s: a final row was marked", name);
+                memcpy(&probs[(size_t)(i * p.c)], &p.exact[(size_t)(i * p.c)], sizeof(float) * (size_t)p.c);
+                pred[(size_t)i] = p.pred_exact[(size_t)i]; eps[(size_t)i] = 0.f; ++refined;
+            }
+        CHECK(rounds < 64, "%s: no convergence", name);
+        if (rounds >= 64) break;
+    }
+    printf("scan %-28s n=%lld c=%d k=%lld: %d rounds, %lld rows refined, threaded == single-threaded\n", name, (long long)n, c, (long long)k, rounds + 1, (long long)refined);
+}
+
+static std::string synthetic_merges(int n_merges, unsigned seed) {
+    // merges over lower-case letters (ids of single bytes are known without the table): "a b", then products of earlier merges
+    std::mt19937 g(seed);
+    std::vector<std::string> syms;
+    for (char ch = 'a'; ch <= 'z'; ++ch) { syms.push_back(std::string(1, ch)); syms.push_back(std::string(1, ch) + "</w>"); }
+    std::string out;
+    for (int m = 0; m < n_merges; ++m) {
+        const std::string& a = syms[g() % syms.size()];
+        const std::string& b = syms[g() % syms.size()];
+        if (a.size() >= 4 && a.compare(a.size() - 4, 4, "</w>") == 0) { --m; continue; }     // an end-of-word symbol cannot be a left part
+        out += a + " " + b + "\n";
+        syms.push_back(a + b);
+    }
+    return out;
+}
+
+static void bpe_cases() {
+    const std::string merges = synthetic_merges(3000, 5);
+    grip_bpe* t = nullptr;
+    CHECK(grip_bpe_create(merges.data(), merges.size(), &t) == 0 && t, "bpe_create");
+    int32_t sot = 0, eot = 0, vocab = 0;
+    CHECK(grip_bpe_special_ids(t, &sot, &eot, &vocab) == 0 && eot == sot + 1 && vocab == eot + 1, "special ids %d %d %d", sot, eot, vocab);
+    // reference encodes, single-threaded, then the same words from 8 threads through the one handle (cache + mutex)
+    std::vector<std::string> words;
+    std::mt19937 g(9);
+    for (int i = 0; i < 400; ++i) {
+        std::string w;
+        const int len = 1 + (int)(g() % 24);
+        for (int j = 0; j < len; ++j) w.push_back((char)('a' + g() % 26));
+        words.push_back(w);
+    }
+    words.push_back(std::string(5000, 'a'));           // a very long word
+    words.push_back("\xc3\xa9t\xc3\xa9");              // non-ASCII bytes
+    std::vector<std::vector<int32_t>> want(words.size());
+    for (size_t i = 0; i < words.size(); ++i) {
+        std::vector<int32_t> ids(words[i].size() + 4);
+        int n_out = -1;
+        CHECK(grip_bpe_encode_word(t, (const uint8_t*)words[i].data(), (int)words[i].size(), ids.data(), (int)ids.size(), &n_out) == 0 && n_out > 0, "encode_word %zu", i);
+        ids.resize((size_t)std::max(n_out, 0));
+        want[i] = ids;
+    }
+    grip_bpe* t2 = nullptr;                               // a fresh handle: cold cache, hammered concurrently
+    CHECK(grip_bpe_create(merges.data(), merges.size(), &t2) == 0, "bpe_create 2");
+    std::vector<std::thread> th;
+    std::vector<int> bad(8, 0);
+    for (int w = 0; w < 8; ++w)
+        th.emplace_back([&, w] {
+            for (int rep = 0; rep < 3; ++rep)
+                for (size_t i = (size_t)w % 3; i < words.size(); i += 1 + (size_t)w % 2) {
+                    std::vector<int32_t> ids(words[i].size() + 4);
+                    int n_out = -1;
+                    const int rc = grip_bpe_encode_word(t2, (const uint8_t*)words[i].data(), (int)words[i].size(), ids.data(), (int)ids.size(), &n_out);
+                    ids.resize((size_t)std::max(n_out, 0));
+                    if (rc != 0 || ids != want[i]) ++bad[(size_t)w];
+                }
+        });
+    for (auto& x : th) x.join();
+    for (int w = 0; w < 8; ++w) CHECK(bad[(size_t)w] == 0, "concurrent encodes: thread %d saw %d wrong results", w, bad[(size_t)w]);
+    // whole texts; a buffer that is too small must fail cleanly, not overrun
+    const char* text = "a photo of a forest, a type of xyzzy   plugh!! 12345 it's";
+    std::vector<int32_t> ids(256, -1);
+    int n_out = -1;
+    CHECK(grip_bpe_encode_ascii(t2, text, (int)strlen(text), ids.data(), 256, &n_out) == 0 && n_out > 0 && n_out < 256, "encode_ascii");
+    const int full = n_out;
+    std::vector<int32_t> tiny((size_t)3, -1);
+    n_out = -1;
+    const int rc_small = grip_bpe_encode_ascii(t2, text, (int)strlen(text), tiny.data(), 3, &n_out);
+    CHECK(rc_small != 0 || n_out <= 3, "encode_ascii wrote past a 3-id buffer (rc %d, n_out %d of %d)", rc_small, n_out, full);
+    n_out = -1;
+    CHECK(grip_bpe_encode_ascii(t2, "", 0, ids.data(), 256, &n_out) == 0 && n_out == 0, "empty text");
+    int32_t one = -1;
+    const int rc_w = grip_bpe_encode_word(t2, (const uint8_t*)words[400].data(), (int)words[400].size(), &one, 1, &n_out);
+    CHECK(rc_w != 0 || n_out <= 1, "encode_word wrote past a 1-id buffer");
+    CHECK(grip_bpe_destroy(t) == 0 && grip_bpe_destroy(t2) == 0, "destroy");
+    // malformed tables: never a crash, either an error or a usable handle
+    const char* broken[] = {"", "\n\n\n", "a", "a b c d\n", "a  \n", " b\n", "\xff\xfe \x80\n", "a b\na b\na b\n", "zz</w> q\n"};
+    for (const char* b : broken) {
+        grip_bpe* u = nullptr;
+        const int rc = grip_bpe_create(b, strlen(b), &u);
+        if (rc == 0 && u) {
+            n_out = -1;
+            grip_bpe_encode_ascii(u, "abc ab a", 8, ids.data(), 256, &n_out);
+            grip_bpe_destroy(u);
+        } else CHECK(u == nullptr, "a failed create must not hand out a handle");
+    }
+    std::string trunc = merges.substr(0, merges.size() / 2 + 1);      // cut in the middle of a line, no terminating NUL inside n_bytes
+    std::vector<char> exact_fit(trunc.begin(), trunc.end());          // heap block of exactly n_bytes: a read past the end is an ASAN error
+    grip_bpe* u = nullptr;
+    if (grip_bpe_create(exact_fit.data(), exact_fit.size(), &u) == 0 && u) grip_bpe_destroy(u);
+    CHECK(grip_bpe_create(nullptr, 0, &u) != 0, "null table accepted");
+    printf("bpe: %zu words x 8 threads, texts, short buffers, %zu malformed tables\n", words.size(), sizeof(broken) / sizeof(broken[0]) + 2);
+}
+
+int main() {
+    // (n * c >= 4 M switches the worker-thread pre-filter on: 40 000 x 102 and 70 000 x 64)
+    scan_case("near-tied, dominant class", 40000, 102, 0.05, 4e-3, 1, true, 16);
+    scan_case("spread rows", 40000, 102, 1.0, 2e-3, 2, false, 16);
+    scan_case("label everything", 40000, 102, 0.6, 2e-3, 3, false, 10000000);
+    scan_case("wide boards", 70000, 64, 0.3, 3e-3, 4, false, 300);
+    scan_case("small (single-threaded path)", 3000, 10, 0.5, 3e-3, 5, false, 3);
+    scan_case("k > n / c", 5000, 7, 0.5, 3e-3, 6, false, 2000);
+    bpe_cases();
+    if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }
+    printf("sanitize driver: all checks passed\n");
+    return 0;
+}

@@ -15,7 +15,7 @@ print("one replay: launches", len(step), "span us", (int(tr[b]["Start_Timestamp"
 agg = collections.OrderedDict()
 prev = t0
 gaps = 0
-with open(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/coop_graph_sequence_r04b.txt", "w") as f:
+with open(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/coop_graph_sequence.txt", "w") as f:
     for r in step:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         f.write(f"{(s - t0) / 1e3:9.1f} gap {(s - prev) / 1e3:6.1f} dur {(e - s) / 1e3:6.1f} {r['Kernel_Name'][:110]}\n")

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Final collection of a round (TAG=r04b): whole GPU suite, rocprofv3 kernel stats + PMC passes + the default bench line, in-situ kernel tables of the three
+# Final collection of a round (TAG=r05a): whole GPU suite, rocprofv3 kernel stats + PMC passes + the default bench line, in-situ kernel tables of the three
 # prompt steps (eager loops under rocprofv3), the graphed CoOp step (replay time + per-kernel table of one replay), SQ counters of the VPT step's kernels
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-T=${TAG:-r04b}
+T=${TAG:-r05}
 mkdir -p $R/gpurun_out
 cd $R
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|rror|FAILED|ERROR" | tail -8 > $R/gpurun_out/gputest_$T.log
@@ -15,7 +15,7 @@ for step in vpt upt coop_feature; do
 done
 cd $R
 python tools/coop_graph_bench.py 2>&1 | tail -n 1 > $R/gpurun_out/coop_graph_bench_$T.txt
-bash tools/run14_r04.sh > $R/gpurun_out/coop_graph_replay_$T.txt 2>&1
-cp $R/gpurun_out/coop_graph_sequence_r04b.txt $R/gpurun_out/coop_graph_sequence_$T.txt 2>/dev/null
+bash tools/coop_graph_replay.sh > $R/gpurun_out/coop_graph_replay_$T.txt 2>&1
+cp $R/gpurun_out/coop_graph_sequence.txt $R/gpurun_out/coop_graph_sequence_$T.txt 2>/dev/null
 bash tools/pmc_sq_vpt.sh $T > /dev/null 2>&1
 cat $R/gpurun_out/gputest_$T.log; tail -3 $R/gpurun_out/collect_$T.log; cat $R/gpurun_out/coop_graph_bench_$T.txt
