@@ -800,7 +800,7 @@ def main():
             "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1),
             "calibration_rows": rs["calibration_rows"], "rounds": rs["rounds"], "scans": rs["scans"], "rows_per_round": rs["refined_per_round"],
             "relative_bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "relative_bound_split_f16": rs["eps_mid"],
-            "largest_deviation_seen_split_f16": rs["max_deviation_mid"], "safety": rs["safety"],
+            "largest_deviation_seen_split_f16": rs["max_deviation_mid"], "safety": rs["safety"], "safety_split_f16": rs.get("safety_mid"),
             "audit_rows": rs["audit_rows"], "audit_board_rows": rs["audit_board_rows"], "audit_max_deviation": rs["audit_max_deviation"],
             "audit_widened_the_bound": rs["audit_widened"], "audits": rs["audits"], "audit_rows_split_f16": rs.get("audit_mid_rows", 0),
             "audit_max_deviation_split_f16": rs.get("audit_max_deviation_mid", 0.0), "unverified_rows": rs["unverified_rows"],

@@ -116,7 +116,7 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
         src = None if path is None else sd       # a checkpoint's tensors are kept for the twin; the synthetic init is regenerated
 
         def build_twin(precision=1):
-            t = CLIP(d, device, exact=precision)
+            t = CLIP(d, device, exact=precision, vision_only=precision == 2)      # the middle tier only ever encodes images
             load_openai_state_dict(t, src if src is not None else {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed).items()})
             return t
         m._twin[1] = build_twin
@@ -139,4 +139,5 @@ def load_openai_state_dict(m: CLIP, sd):
         for k, p in own.items():
             p.copy_(sd[k].reshape(p.shape).to(p.dtype))
     m.visual.tower.finalize()
-    m.tower.finalize()
+    if m.tower is not None:
+        m.tower.finalize()

@@ -52,7 +52,8 @@ class _TowerModule(nn.Module):
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
-        self.tower._finalized = False
+        if self.tower is not None:
+            self.tower._finalized = False
 
 
 class VisionTransformer(_TowerModule):
@@ -107,7 +108,7 @@ class Transformer(nn.Module):
 
 
 class CLIP(_TowerModule):
-    def __init__(self, d: ClipDims, device="cuda", exact=False):
+    def __init__(self, d: ClipDims, device="cuda", exact=False, vision_only=False):
         super().__init__()
         self.dims = d
         self.precision = int(exact)        # 0 f16 towers, 1 f32 towers, 2 split-f16 towers (include/grip_amd.h: grip_dims.precision)
@@ -115,8 +116,12 @@ class CLIP(_TowerModule):
         self.context_length = d.context_length
         self.vocab_size = d.vocab_size
         self.visual = VisionTransformer(d, device, exact=exact)
-        self.add_module("token_embedding", _Embedding())
-        self._bind(engine.text_tower(d, device, exact=exact))
+        self.vision_only = bool(vision_only)     # the split-f16 twin: the middle tier re-encodes IMAGES only (no text tower: its blob + #S copies would sit unused)
+        if vision_only:
+            self._tower = [None]
+        else:
+            self.add_module("token_embedding", _Embedding())
+            self._bind(engine.text_tower(d, device, exact=exact))
         self.logit_scale = _frozen(torch.ones([], device=device) * math.log(1 / 0.07))
         self._twin = [None, None]       # [the exact (f32) twin, a callable that builds it]: set by clip.load, out of nn.Module's registry
         self._split = [None, None]      # the same for the split-f16 twin
@@ -154,6 +159,8 @@ class CLIP(_TowerModule):
         return self.visual(image)
 
     def encode_text(self, text):
+        if self.tower is None:
+            raise engine.native.GripError("this CLIP holds a vision tower only (the split-f16 twin of the refinement's middle tier)")
         return self.tower.text_forward(text)[0]
 
     def forward(self, image, text):

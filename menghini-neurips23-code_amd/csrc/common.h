@@ -202,7 +202,7 @@ int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);
 // split-f16 tier (gemm_split.hip; GemmArgs.f32 == 2): A and W in the split layout ([32 x hi | 32 x lo'] f16 per 32 consecutive k, row pitch
 // 4 K bytes), f32 bias / residual / output -- EPI_BIAS_GELU_F16 writes its output in the split layout (it feeds the next split GEMM)
 int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s);
-int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight = 0);   // weights carry gemm_split_weight_scale()
+int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight = 0, int* overflow_flag = nullptr);   // weights carry gemm_split_weight_scale()
 float gemm_split_weight_scale();
 
 // Activation buffers are f16 (default) or f32 (exact mode): the row kernels take untyped pointers plus the flag.  f32 == 2 (split-f16

@@ -1,26 +1,37 @@
 // Split-f16 GEMM (dims.precision = 2, the MIDDLE tier of screen-and-refine): C[M,N] = epi(A[M,K] * W[N,K]^T) to ~22 mantissa bits
 // on the f16 matrix pipes.  Every operand element x is carried as two f16 numbers
-//     hi = f16(x),   lo' = f16((x - hi) * 2^11)            (x - hi is exact in f32; |lo'| <= |x|: same range as hi, never subnormal
-//                                                            where hi is normal, so nothing here depends on subnormal handling)
-// and the product is formed from THREE v_mfma_f32_16x16x32_f16 per fragment pair with f32 accumulation:
-//     main += a_hi w_hi;    corr += a_hi w_lo' + a_lo' w_hi;    C = main + 2^-11 corr        (dropped: a_lo w_lo, 2^-22 relative)
+//     hi = f16(x),   lo = f16(x - hi)                       (x - hi is exact in f32)
+// and the product is formed from THREE v_mfma_f32_16x16x32_f16 per fragment pair into ONE f32 accumulator:
+//     acc += a_hi w_hi + a_hi w_lo + a_lo w_hi                                             (dropped: a_lo w_lo, 2^-22 relative)
 // so a term's relative error is ~3 x 2^-23 against f32's 2^-24: the deviations of the tower's probabilities from the f32 twin's are
 // of the size two f32 summation orders differ by (measured: DESIGN.md 10.2), 100x below the f16 towers', at a third of the f16 MFMA
 // rate instead of a sixteenth (v_mfma_f32_16x16x4_f32).  The reference decides on fp32 values (utils/clip_pseudolabels.py:38-41,
 // 73-101); this tier only SCREENS for it more finely -- whatever it cannot decide still goes to the f32 tower.
 //
+// THE DEFAULT BUILD (GRIP_SPLIT_LO_SCALE == 1, `gemm_split1_kernel` below) keeps the lo parts UNSCALED, so they are often f16 SUBNORMALS:
+// it relies on gfx950's f16 MFMA taking subnormal inputs unflushed (measured, tools/micro/mfma_denorm.hip; this file is built for gfx950
+// only -- the #error below).  To keep the lo part of a typical weight (|w| ~ 0.02) normal, WEIGHTS are stored scaled by 2^8 (SP1_W_SCALE,
+// exact) and the epilogue multiplies by 2^-8; a weight with |w| >= 255.9 would overflow its hi part: grip_tower_finalize checks the range
+// and fails (launch_split_rows' overflow flag).  Activations are unscaled; an activation lo below the f16 normal range is quantised to
+// 2^-24 absolute.  The developer variant GRIP_SPLIT_LO_SCALE = 2048 (`gemm_split_kernel`: lo' = f16((x - hi) * 2^11), two accumulators,
+// 256 x 128 tile, nothing subnormal where hi is normal) is kept for A/B; it measured 10 - 15 % slower.
+//
 // Data layout ("split layout"), activations and weights alike: row-major, per row and per group of 32 consecutive k one 128-byte
-// line [32 x hi | 32 x lo'] -- the row pitch equals an f32 row's (4 K bytes), a K step of the GEMM moves whole cache lines, and
+// line [32 x hi | 32 x lo] -- the row pitch equals an f32 row's (4 K bytes), a K step of the GEMM moves whole cache lines, and
 // the LDS image of a stage is byte for byte gemm_f32.hip's (128-byte rows, 16-byte chunk index XOR (row & 7) on the DMA source
 // address and on the ds_read_b128 address: conflict-free).  A lane's MFMA fragment (8 consecutive k of one row) is chunk
 // (lane >> 4) of the row's hi half and chunk 4 + (lane >> 4) of its lo half: one ds_read_b128 each.
 //
-// Kernel: 256 x 128 block tile, 8 waves as 4 x 2 (64 x 64 per wave = 4 x 4 fragments, 2 x 64 accumulator registers), K staged 32
-// wide in a 3-slot LDS ring of 48 KiB stages fed by global_load_lds with counted vmcnt (two stages in flight), one workgroup per CU.
-// Operands are swapped (W fragment first) so a lane ends with four consecutive output columns of one row.
+// Kernels: default = 256 x 256 tile, 8 waves as 2 x 4 (128 x 64 per wave), two 64-KiB stages (see `gemm_split1_kernel`); scaled variant =
+// 256 x 128 tile, 8 waves as 4 x 2, K staged 32 wide in a 3-slot ring of 48 KiB stages with counted vmcnt.  Operands are swapped
+// (W fragment first) so a lane ends with four consecutive output columns of one row.
 #include <math.h>
 
 #include "common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "gemm_split.hip relies on gfx950 MFMA semantics (unflushed f16 subnormal inputs); build with --offload-arch=gfx950 only"
+#endif
 
 #define SPL_BM 256
 #define SPL_BN 128
@@ -370,13 +381,20 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
 
 // x [rows, K] f32 (row pitch ld_in floats) -> split layout [rows, K/32, 64] halfs (weights at grip_tower_finalize; activations whose
 // producer does not write the layout itself).  One thread per 4 consecutive k.
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, half_t* __restrict__ out, int64_t rows, int K, int64_t ld_in, float scale) {
+// `overflow` (weights only, may be null): set to 1 when a scaled element leaves the finite f16 range -- its hi part would be inf and every row
+// of the tower non-finite (that used to end as a silent escalation of the whole pool to the f32 tower).
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, half_t* __restrict__ out, int64_t rows, int K, int64_t ld_in, float scale,
+                                                         int* __restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int k4 = K >> 2;
     if (i >= rows * k4) return;
     const int64_t r = i / k4;
     const int c = (int)(i - r * k4) * 4;
     const f32x4 v = *(const f32x4*)(x + r * ld_in + c) * scale;
+    if (overflow) {
+        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (!(m < 65520.0f)) *overflow = 1;            // 65520 rounds to inf in f16; NaN lands here too (benign race: every writer stores 1)
+    }
     store4(SplitRow{out + r * 2 * (int64_t)K}, c >> 2, v);
 }
 
@@ -388,10 +406,11 @@ float gemm_split_weight_scale() {
 #endif
 }
 
-int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight) {
+int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight, int* overflow_flag) {
     GRIP_REQUIRE(K % 32 == 0 && rows > 0 && ld_in >= K && ld_in % 4 == 0, "split_rows: need K %% 32 == 0 (rows=%lld K=%d ld=%lld)", (long long)rows, K, (long long)ld_in);
     const int64_t n = rows * (K / 4);
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (half_t*)out, rows, K, ld_in, is_weight ? gemm_split_weight_scale() : 1.0f);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (half_t*)out, rows, K, ld_in, is_weight ? gemm_split_weight_scale() : 1.0f,
+                       overflow_flag);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }

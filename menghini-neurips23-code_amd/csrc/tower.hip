@@ -386,13 +386,26 @@ extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
             if ((rc = launch_ln_fold_weights(t->w16 + w.in_w, F + w.ln1_g, F + w.ln1_b, F + w.in_b, t->w16 + w.in_wG, F + w.in_cs, F + w.in_bb, 3 * d, d, s))) return rc;
             if ((rc = launch_ln_fold_weights(t->w16 + w.fc_w, F + w.ln2_g, F + w.ln2_b, F + w.fc_b, t->w16 + w.fc_wG, F + w.fc_cs, F + w.fc_bb, 4 * d, d, s))) return rc;
         }
-    if (t->split)   // split-layout copies of the block weights (the f32 originals stay: patch embedding and the final projection use them)
+    if (t->split) { // split-layout copies of the block weights (the f32 originals stay: patch embedding and the final projection use them)
+        int* flag = nullptr;        // raised by the split kernel when a scaled weight leaves the f16 range (finalize is a one-off: a sync here is fine)
+        GRIP_CHECK_HIP(hipMalloc((void**)&flag, sizeof(int)));
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+        rc = e == hipSuccess ? GRIP_OK : GRIP_ERR_HIP;
         for (const LayerW& w : t->L.layer) {
-            if ((rc = launch_split_rows((const float*)t->wop(w.in_w), t->wop(w.in_wS), 3 * d, d, d, s, 1))) return rc;
-            if ((rc = launch_split_rows((const float*)t->wop(w.out_w), t->wop(w.out_wS), d, d, d, s, 1))) return rc;
-            if ((rc = launch_split_rows((const float*)t->wop(w.fc_w), t->wop(w.fc_wS), 4 * d, d, d, s, 1))) return rc;
-            if ((rc = launch_split_rows((const float*)t->wop(w.proj_w), t->wop(w.proj_wS), d, 4 * d, 4 * d, s, 1))) return rc;
+            if (rc) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.in_w), t->wop(w.in_wS), 3 * d, d, d, s, 1, flag))) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.out_w), t->wop(w.out_wS), d, d, d, s, 1, flag))) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.fc_w), t->wop(w.fc_wS), 4 * d, d, d, s, 1, flag))) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.proj_w), t->wop(w.proj_wS), d, 4 * d, 4 * d, s, 1, flag))) break;
         }
+        int over = 0;
+        if (!rc && (hipMemcpyAsync(&over, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = GRIP_ERR_HIP;
+        (void)hipFree(flag);
+        if (rc == GRIP_ERR_HIP) { grip_set_error("tower_finalize: HIP error while splitting the weights"); return rc; }
+        if (rc) return rc;
+        GRIP_REQUIRE(!over, "tower_finalize: a block weight times %g leaves the f16 range (or is not finite): split-f16 towers (precision 2) need |w| < %g",
+                     (double)gemm_split_weight_scale(), 65504.0 / (double)gemm_split_weight_scale());
+    }
     if ((rc = launch_transpose(t->wop(t->L.proj), t->wop(t->L.projT), f, d, t->D.embed_dim, t->D.embed_dim, s))) return rc;
     t->finalized = true;
     return GRIP_OK;

@@ -104,6 +104,8 @@ def leaderboard(probs, pred, paths, class_labels, k):
 # ------------------------------------------------------------------------------------------ screen and refine
 REFINE_CALIB_ROWS = 256     # rows re-encoded exactly up front to measure the cheaper tiers' deviation on THIS pool
 REFINE_SAFETY = 2.0         # bound = safety x the largest deviation seen on any row re-encoded so far (it only ever grows)
+REFINE_SAFETY_MID = 8.0     # the same for the middle tier: its bound rests on a quarter of the calibration rows (an f32 row costs 2.5 split-f16 ones), so it is
+                            # given four times the margin instead -- at 1e-5-sized deviations the extra band holds a handful of rows
 REFINE_ESCALATE_AFTER = 8   # rounds after which whatever is still un-refined moves up a tier in one go (pathological pools only, see refine_scan)
 REFINE_AUDIT_ROWS = 256     # un-refined rows re-encoded AFTER the scan certified its lists, to check the bound they were trusted to ($GRIP_REFINE_AUDIT)
 REFINE_MAX_AUDITS = 4       # audits that may each widen the bound before everything left is simply re-encoded
@@ -192,8 +194,10 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
             if idx.size == 0:
                 return
         # the middle tier's value is itself only known to eps[1]: a screen value within d of it is within d (1 + eps1) + eps1 of the truth
-        d = _deviation(probs[idx], pm, abs_eps)
-        dev[0] = max(dev[0], d * (1.0 + eps[1]) + eps[1])
+        fin = np.isfinite(probs[idx]).all(axis=1)      # (a non-finite screen row says nothing about the tier's accuracy: as in to_exact)
+        if fin.any():
+            d = _deviation(probs[idx[fin]], pm[fin], abs_eps)
+            dev[0] = max(dev[0], d * (1.0 + eps[1]) + eps[1])
         probs[idx] = pm
         pred[idx] = am
         level[idx] = 1
@@ -208,7 +212,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         to_exact(hi)
 
     def bound(lv):
-        return min(safety * dev[lv], _EPS_CAP)
+        return min((safety if lv == 0 else max(safety, REFINE_SAFETY_MID)) * dev[lv], _EPS_CAP)
 
     stats = {"rows": n, "calibration_rows": 0, "rounds": 0, "scans": 0, "audits": 0, "audit_rows": 0, "audit_board_rows": 0, "audit_max_deviation": 0.0,
              "audit_widened": False}
@@ -217,8 +221,12 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         return np.empty(0, np.int32), np.empty(0, np.int32), dict(stats, rows_refined=0, rows_mid=0, rows_exact=0, eps=0.0, eps_mid=0.0, max_deviation=0.0,
                                                                     max_deviation_mid=0.0, refined_per_round=[], safety=float(safety), unverified_rows=0,
                                                                     observed_rows=0, tiers=2 + (mid_rows is not None))
+    broken = np.flatnonzero(~np.isfinite(probs).all(axis=1))       # rows the screen overflowed on (f16 range): exact at once, outside every bound --
+    stats["nonfinite_screen_rows"] = int(broken.size)               # and BEFORE the calibration, so that none of them can enter a measured deviation
+    to_exact(broken, measure=False)
     # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than 16 (a bound from one or two rows is no bound)
     cal = np.unique(np.linspace(0, n - 1, min(n, max(16, min(calib, n // 16)))).astype(np.int64))
+    cal = cal[level[cal] == 0]          # (a row the screen overflowed on is final already and measures nothing)
     if mid_rows is not None:
         # With a middle tier the screen's bound is calibrated against IT (every calibration row; its own error is folded in), and the middle
         # tier's bound against the exact tower on every fourth calibration row (at least 16): its deviations are f32-rounding-sized and tightly
@@ -240,9 +248,6 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         to_exact(cal)
     stats["calibration_rows"] = int(cal.size)
     stats["calibration_rows_exact"] = int((level[cal] == 2).sum())
-    broken = np.flatnonzero(~np.isfinite(probs).all(axis=1))       # rows the screen overflowed on (f16 range): exact at once, outside every bound
-    stats["nonfinite_screen_rows"] = int(broken.size)
-    to_exact(broken, measure=False)
     eps = [bound(0), bound(1)]
     per_round = []
     g = np.random.default_rng(1000003 * n + int(min(k, 1 << 30)))      # the audit's draw: a function of the problem only (identical on every rank)
@@ -308,7 +313,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         stats["rounds"] += 1
         eps = [max(eps[0], bound(0)), max(eps[1], bound(1))]
     stats.update(rows_refined=int((level > 0).sum()), rows_mid=int(n_mid), rows_exact=int(n_exact), refined_per_round=per_round, eps=float(eps[0]),
-                 eps_mid=float(eps[1]), max_deviation=float(dev[0]), max_deviation_mid=float(dev[1]), safety=float(safety),
+                 eps_mid=float(eps[1]), max_deviation=float(dev[0]), max_deviation_mid=float(dev[1]), safety=float(safety), safety_mid=float(max(safety, REFINE_SAFETY_MID)),
                  unverified_rows=int((level == 0).sum()), observed_rows=int((level > 0).sum()), tiers=2 + (mid_rows is not None), abs_eps=float(abs_eps))
     return img, cls, stats
 
@@ -345,7 +350,12 @@ def mid_tower(clip_model, n_rows):
         return None
     if clip_model.dims.vision_width % 256:      # the split GEMM's 256 x 256 tiles (grip_tower_create refuses other widths at precision 2)
         return None
-    twin = clip_model.split_twin()
+    try:
+        twin = clip_model.split_twin()
+    except engine.native.GripError as e:        # the tier is an optimisation: without it the screen's rows go straight to the f32 tower
+        import logging
+        logging.getLogger(__name__).warning("split-f16 middle tier unavailable (%s): refining with the f32 tower only", e)
+        return None
     return None if twin is None else twin.visual.tower
 
 
