@@ -223,27 +223,28 @@ class Loop:
         img, cls = self.pseudolabel_pass(self.m, a.streams)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        # (iv) prompt steps over the selected pairs that live in this rank's shard
+        # (iv) prompt steps over the selected pairs, data-parallel as the product's trainer is (TrainingStrategy._loader -> dist.rank_batches = accelerate's
+        # even sharding, textual_prompt.py:131 / :239): the M pairs in list order are cut into batches of `batch`, batch j goes to rank j % ws (tail padded
+        # from the start), gradients are averaged.  The pool is resident per rank, so the selected images travel once per pass: every rank contributes the
+        # ones of its own shard to one all-gather (dist.allgather_selected; nothing moves at N = 1).
         lo = self.rank * a.pool
-        mine = (img >= lo) & (img < lo + a.pool)
-        my_img = torch.from_numpy(img[mine] - lo).long().to(self.device)
-        my_lab = torch.from_numpy(cls[mine]).to(self.device)
-        n_steps = math.ceil(len(img) / (a.batch * self.ws)) if len(img) else 0
-        # the batch index of every step of this pass at once (one gather per look-ahead group instead of six tiny launches per step)
-        own = len(my_img) > 0
-        if own:
-            order = my_img[torch.arange(n_steps * a.batch, device=self.device) % len(my_img)]
-            labels = my_lab[torch.arange(n_steps * a.batch, device=self.device) % len(my_img)]
-            w_row = torch.full((a.batch,), 1.0 / a.batch, device=self.device)
-        else:   # no selected image lives in this rank's shard: same work, zero weight (it still joins the all-reduce)
-            order = torch.arange(a.batch, device=self.device).repeat(n_steps)
-            labels = torch.zeros(n_steps * a.batch, dtype=torch.int32, device=self.device)
-            w_row = torch.zeros(a.batch, device=self.device)
+        uniq = np.unique(img) if len(img) else np.empty(0, np.int64)
+        mine = torch.from_numpy(uniq[(uniq >= lo) & (uniq < lo + a.pool)] - lo).long().to(self.device)
+        sel = gdist.allgather_selected(self.pool[mine].flatten(1), uniq, self.n_total).view(-1, *self.pool.shape[1:]) if len(uniq) else self.pool[:0]
+        my_batches = gdist.rank_batches(range(len(img)), a.batch)
+        n_steps = len(my_batches)
+        at = torch.from_numpy(np.searchsorted(uniq, img)).to(self.device)           # pair -> row of `sel`
+        pair_lab = torch.from_numpy(cls).to(self.device)
+        flat = torch.tensor([i for b in my_batches for i in b], dtype=torch.long, device=self.device)
+        order, labels = at[flat], pair_lab[flat]
+        sizes = [len(b) for b in my_batches]          # (one process keeps a ragged last batch, like the trainer's loader)
+        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+        w_rows = {n: torch.full((n,), 1.0 / n, device=self.device) for n in set(sizes)}
 
         def batches():
             for t in range(n_steps):
-                sl = slice(t * a.batch, (t + 1) * a.batch)
-                yield self.pool[order[sl]], labels[sl], w_row
+                sl = slice(starts[t], starts[t + 1])
+                yield sel[order[sl]], labels[sl], w_rows[sizes[t]]
 
         if a.lookahead > 1:     # frozen image tower encoded `lookahead` steps at a time (steps.lookahead_image_features)
             for f, y, w in steps.lookahead_image_features(self.m, batches(), a.lookahead):
@@ -786,9 +787,10 @@ def main():
                    "train_image_lookahead": f"{args.lookahead} steps: the frozen image tower encodes the batches of {args.lookahead} consecutive prompt steps in one forward "
                                             "(every image is encoded every time a step uses it; nothing is cached)" if args.lookahead > 1 else "1 (encode inside every step)",
                    "last_block_rows_only": f_img_x != F_IMG,
-                   "train_sharding": "each rank steps on the selected images of its OWN shard (zero-weight rows where it owns none), batch 16 per rank; "
+                   "train_sharding": "the product trainer's sharding (dist.rank_batches = accelerate's even batches): batch j of the selected pairs in list order goes to rank j % N, "
+                                     "batch 16 per rank, tail padded from the start; the selected images are all-gathered once per pass (each rank contributes its shard's); "
                                      "prompt gradients are mean-all-reduced every step -- not one global batch split over ranks",
-                   "collectives": "RCCL all_gather_into_tensor of [pool, 512] f32 embeddings per pass + all_reduce of the 32 KB prompt gradient per step"
+                   "collectives": "RCCL all_gather_into_tensor of [pool, 512] f32 embeddings per pass (+ one of the refined rows per round, + one of the <= k C selected images for the prompt steps) + all_reduce of the 32 KB prompt gradient per step"
                                   if not on_host else "gloo through host memory (GRIP_DIST_BACKEND=gloo)"},
         "ranks_seen": seen,
         "stage_seconds_over_ranks": stages,

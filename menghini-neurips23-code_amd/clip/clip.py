@@ -86,12 +86,13 @@ def _preprocess(n_px, device):
     return ClipPreprocess(n_px, device)
 
 
-def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0, exact=None):
+def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0, exact=None, synthetic="standard"):
     """(model, preprocess).  Weights: $CLIP_WEIGHTS (a torch-saved OpenAI state_dict) when set,
     else the seeded synthetic init of grip_amd.weights (no checkpoints exist offline).
     exact=True (or GRIP_EXACT=1): f32 towers -- weights, activations, attention and residual stream in fp32, the
     arithmetic the reference's CPU path uses (clip.load(..., device="cpu") keeps fp32) -- for index-exact comparison of
-    the pseudolabel lists; inference only, ~1/10 of the f16 throughput."""
+    the pseudolabel lists; inference only, ~1/10 of the f16 throughput.
+    synthetic="stress": the synthetic init with outlier channels and an image-dependent f16 overflow (weights.stress_state_dict: tests / bench only)."""
     d = _cfg.get_dims(name)
     if exact is None:
         exact = os.environ.get("GRIP_EXACT", "0") == "1"
@@ -110,23 +111,27 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
     else:
         _warn_once("weights", "clip.load: no $CLIP_WEIGHTS -- using SYNTHETIC seeded random-init weights (accuracies are meaningless)")
         PROVENANCE["weights"] = "synthetic"
-        sd = {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed).items()}    # a second load of the same synthetic model reuses the arrays
+        if synthetic not in ("standard", "stress"):
+            raise ValueError(f"synthetic={synthetic!r}: expected 'standard' or 'stress'")
+        if synthetic != "standard":
+            PROVENANCE["weights"] = "synthetic-" + synthetic
+        sd = {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed, synthetic).items()}    # a second load of the same synthetic model reuses the arrays
     load_openai_state_dict(m, sd)
     if not exact:
         src = None if path is None else sd       # a checkpoint's tensors are kept for the twin; the synthetic init is regenerated
 
         def build_twin(precision=1):
             t = CLIP(d, device, exact=precision, vision_only=precision == 2)      # the middle tier only ever encodes images
-            load_openai_state_dict(t, src if src is not None else {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed).items()})
+            load_openai_state_dict(t, src if src is not None else {k: torch.from_numpy(v) for k, v in _synthetic_sd(name, d, seed, synthetic).items()})
             return t
         m._twin[1] = build_twin
         m._split[1] = lambda: build_twin(2)
     return m, _preprocess(d.image_resolution, device)
 
 
-def _synthetic_sd(name, d, seed):
-    if _SD_CACHE.get("key") != (name, seed):
-        _SD_CACHE.update(key=(name, seed), sd=_weights.init_state_dict(d, seed))
+def _synthetic_sd(name, d, seed, variant="standard"):
+    if _SD_CACHE.get("key") != (name, seed, variant):
+        _SD_CACHE.update(key=(name, seed, variant), sd=_weights.stress_state_dict(d, seed) if variant == "stress" else _weights.init_state_dict(d, seed))
     return _SD_CACHE["sd"]
 
 

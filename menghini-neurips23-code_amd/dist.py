@@ -195,6 +195,92 @@ def allgather_selected(local_rows, idx, n_total):
     return out[torch.as_tensor(pick, device=out.device)]
 
 
+# ------------------------------------------------------------------------------------------ data-parallel batches (the trainer's loops)
+def rank_batches(order, batch_size, rank=None, world_size=None):
+    """The index batches rank `rank` of `world_size` processes walks in one epoch over the samples `order` -- what HF accelerate's prepared
+    DataLoader gives the reference's loops (`accelerator.prepare(train_loader)`, e.g. textual_prompt.py:239; accelerate's BatchSamplerShard with
+    split_batches=False, even_batches=True): EVERY rank runs full batches of `batch_size` (so the global batch is world_size x batch_size),
+    batch j of the epoch goes to rank j % world_size, a ragged last batch is completed with samples from the START of the epoch's order and
+    further such batches are appended until the count divides by world_size (the duplicates are what test_predictions drops again,
+    textual_prompt.py:291-294).  One process: the plain batches, ragged tail kept.  Held equal to accelerate's sampler in tests/test_dist_gloo.py."""
+    if rank is None:
+        rank, world_size = world()
+    order = [int(i) for i in order]
+    batches = [order[i: i + batch_size] for i in range(0, len(order), batch_size)]
+    if world_size == 1 or not batches:
+        return batches
+    fill = [i for b in batches[:world_size] for i in b]       # the padding cycles through the epoch's first world_size batches
+    while len(fill) < world_size * batch_size:
+        fill = fill + fill
+    at = batch_size - len(batches[-1])
+    batches[-1] = batches[-1] + fill[:at]
+    while len(batches) % world_size:
+        batches.append(fill[at: at + batch_size])
+        at += batch_size
+    return batches[rank::world_size]
+
+
+class RankBatchSampler:
+    """`batch_sampler` of the trainer's DataLoaders: a fresh permutation per epoch from a generator that is seeded alike on every rank
+    (shuffle) or the dataset order, dealt to the ranks by rank_batches."""
+
+    def __init__(self, n, batch_size, shuffle, seed=0):
+        self.n, self.batch_size = int(n), int(batch_size)
+        self.generator = torch.Generator().manual_seed(seed) if shuffle else None
+
+    def __iter__(self):
+        order = torch.randperm(self.n, generator=self.generator).tolist() if self.generator is not None else range(self.n)
+        return iter(rank_batches(order, self.batch_size))
+
+    def __len__(self):
+        return len(rank_batches(range(self.n), self.batch_size))
+
+
+def gather_in_dataset_order(local_rows, n, batch_size):
+    """Per-sample rows every rank computed for ITS batches of the un-shuffled dataset (rank_batches(range(n), batch_size), concatenated in
+    order) -> [n, ...] rows in dataset order on every rank: `accelerator.gather` + the de-duplication of the padded tail
+    (textual_prompt.py:285-294; a duplicated sample's rows are identical, the first occurrence is kept)."""
+    rank, ws = world()
+    if ws == 1:
+        return local_rows[:n]
+    per_rank = [[i for b in rank_batches(range(n), batch_size, r, ws) for i in b] for r in range(ws)]
+    m = len(per_rank[0])
+    assert all(len(p) == m for p in per_rank) and local_rows.shape[0] == m, (local_rows.shape, [len(p) for p in per_rank])
+    flat = allgather_rows(local_rows.reshape(m, -1), ws * m, m)
+    import numpy as np
+    uniq, first = np.unique(np.array([i for p in per_rank for i in p], dtype=np.int64), return_index=True)      # position of each sample's FIRST occurrence
+    assert len(uniq) == n and uniq[0] == 0 and uniq[-1] == n - 1
+    return flat[torch.from_numpy(first).to(flat.device)].reshape((n,) + tuple(local_rows.shape[1:]))
+
+
+def broadcast_array_(a, src=0):
+    """A host numpy array (same shape / dtype on every rank) overwritten with rank `src`'s content."""
+    rank, ws = world()
+    if ws == 1:
+        return a
+    t = torch.from_numpy(a)
+    if _via_host():
+        dist.broadcast(t, src=src)
+    else:                                   # RCCL moves device memory
+        d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.broadcast(d, src=src)
+        t.copy_(d.cpu())
+    return a
+
+
+def allreduce_sum_(t):
+    """In-place sum of a small tensor over the ranks (epoch statistics)."""
+    if not is_dist() or world()[1] == 1:
+        return t
+    if _via_host() and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
 def allreduce_mean_(tensors):
     """In-place mean all-reduce of the (tiny) prompt gradients, flattened into one message."""
     rank, ws = world()

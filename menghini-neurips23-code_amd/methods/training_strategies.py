@@ -209,8 +209,13 @@ class TrainingStrategy:
 
     # ------------------------------------------------------------------ loops
     def _loader(self, data, shuffle):
-        g = torch.Generator().manual_seed(0)
-        return torch.utils.data.DataLoader(data, batch_size=int(self.config.BATCH_SIZE), shuffle=shuffle, generator=g if shuffle else None)
+        """Data-parallel like the reference under `accelerate launch` (methods_config/accelerate_config.yml: MULTI_GPU): every rank gets its OWN
+        batches of BATCH_SIZE -- batch j of the epoch's order goes to rank j % world_size, the tail is padded with samples from the start
+        (dist.rank_batches = accelerate's BatchSamplerShard; `accelerator.prepare(loader)`, e.g. textual_prompt.py:239) -- so N ranks take one
+        optimizer step on N x BATCH_SIZE samples with the gradients averaged (DDP behind accelerator.backward, :131).  The shuffle seed is the same
+        on every rank (`LOADER_SEED`, default 0: unpinnable upstream)."""
+        sampler = gdist.RankBatchSampler(len(data), int(self.config.BATCH_SIZE), shuffle, seed=int(getattr(self.config, "LOADER_SEED", 0)))
+        return torch.utils.data.DataLoader(data, batch_sampler=sampler)
 
     def _class_space(self, only_seen):
         classes = self.seen_classes if only_seen else self.classes
@@ -273,8 +278,15 @@ class TrainingStrategy:
             correct += (ids[g.logits.argmax(1)] == label).sum()
             count += len(label)
         self.update_scheduler()
-        n_batches = max(len(train_loader), 1)
-        return float(total) / n_batches, int(correct) / max(count, 1)
+        return self._epoch_stats(total, correct, count, len(train_loader))
+
+    def _epoch_stats(self, total, correct, count, n_batches):
+        """(mean loss per batch, accuracy) over ALL ranks' batches: the reference gathers predictions and labels of every rank, padded duplicates
+        included, for the accuracy (textual_prompt.py:146-150); its loss stays per rank -- here it is the mean over the ranks."""
+        t = torch.tensor([float(total), float(correct), float(count), float(n_batches)], dtype=torch.float64, device=self.device)
+        gdist.allreduce_sum_(t)
+        total, correct, count, n_batches = t.tolist()
+        return total / max(n_batches, 1.0), correct / max(count, 1.0)
 
     def _train_epoch_eager(self, train_loader, classes, ids, lut, accum):
         total, correct, count = 0.0, 0, 0
@@ -292,11 +304,14 @@ class TrainingStrategy:
             correct += int((ids[logits.argmax(1)] == label).sum())
             count += len(label)
         self.update_scheduler()
-        return total / max(len(train_loader), 1), correct / max(count, 1)
+        return self._epoch_stats(total, correct, count, len(train_loader))
 
     @torch.no_grad()
     def predict(self, data, classes):
-        """Global label ids predicted for every item of `data`, logits [N, len(classes)] on the CPU."""
+        """Global label ids predicted for every item of `data`, logits [N, len(classes)] on the CPU, in dataset order on every rank.  Sharded like the
+        reference's evaluation loops under accelerate (`accelerator.prepare(test_loader)`, textual_prompt.py:239): each rank runs its own batches
+        (dist.rank_batches over the dataset order), the per-rank logits are all-gathered and the samples accelerate's even sharding duplicated
+        are dropped again (:285-294)."""
         ids = torch.tensor([self.label_to_idx[c] for c in classes], device=self.device)
         outs = []
         for batch in self._loader(data, False):
@@ -304,7 +319,8 @@ class TrainingStrategy:
             image_features, text_features = self.features(img, classes)
             logits, _, am, _ = cosine_head(image_features, text_features, self.scale(), want_probs=False)
             outs.append(logits)
-        logits = torch.cat(outs)
+        logits = torch.cat(outs) if outs else torch.empty(0, len(classes), device=self.device)
+        logits = gdist.gather_in_dataset_order(logits, len(data), int(self.config.BATCH_SIZE))
         return ids[logits.argmax(1)].cpu(), logits.cpu()
 
     def _run_validation(self, val_data, only_seen=False):

@@ -135,6 +135,56 @@ def _deviation(approx, better, abs_eps):
     return float(np.max(r))
 
 
+def scan_placement():
+    """Where the bounded scan of a multi-rank pass runs: "root" (default) -- rank 0 scans with the CPUs of the whole node and broadcasts lists and
+    marks -- or "replicated" (every rank scans: what rounds 1-4 did).  The scan is sequential and does not shard; replicated, the g ranks
+    of a node run it at the same moment on 1/g of the CPUs each.  $GRIP_SCAN_PLACEMENT."""
+    v = os.environ.get("GRIP_SCAN_PLACEMENT", "root")
+    if v not in ("root", "replicated"):
+        raise ValueError(f"GRIP_SCAN_PLACEMENT={v!r}: expected 'root' or 'replicated'")
+    return v
+
+
+def _usable_cpus():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return n
+
+
+def scan_bounded(probs, pred, ranks, rel, k, abs_eps):
+    """engine.leaderboard_scan_bounded for the current process group: one rank, or placement "replicated": the local scan.  Placement "root": rank 0
+    runs it on every CPU the process may use (the native default divides them by $LOCAL_WORLD_SIZE) and the other ranks receive (img, cls, ambiguous)
+    in one broadcast of k C + N / 4 words -- they spend no CPU on it and cannot disagree with rank 0 (tests/test_dist_gloo.py)."""
+    rank, ws = gdist.world()
+    if ws == 1 or scan_placement() != "root":
+        return engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps)
+    n, c = probs.shape
+    cap = n if int(k) == K_ALL else c * max(1, min(int(k), n))
+    words = (n + 3) // 4
+    buf = np.zeros(1 + 2 * cap + words, dtype=np.int32)
+    if rank == 0:
+        own = "GRIP_SCAN_THREADS" not in os.environ
+        if own:
+            os.environ["GRIP_SCAN_THREADS"] = str(min(16, _usable_cpus()))
+        try:
+            img, cls, amb = engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps)
+        finally:
+            if own:
+                del os.environ["GRIP_SCAN_THREADS"]
+        buf[0] = len(img)
+        buf[1: 1 + len(img)] = img
+        buf[1 + cap: 1 + cap + len(cls)] = cls
+        buf[1 + 2 * cap:].view(np.uint8)[:n] = amb
+    gdist.broadcast_array_(buf)
+    m = int(buf[0])
+    return buf[1: 1 + m].copy(), buf[1 + cap: 1 + cap + m].copy(), buf[1 + 2 * cap:].view(np.uint8)[:n].astype(bool)
+
+
 def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safety=REFINE_SAFETY, max_rounds=64, mid_rows=None,
                 audit=None, abs_eps=REFINE_ABS_EPS):
     """Leaderboard lists of the reference's fp32 scan from probabilities of the f16 towers (utils/clip_pseudolabels.py:38-112).
@@ -253,7 +303,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     g = np.random.default_rng(1000003 * n + int(min(k, 1 << 30)))      # the audit's draw: a function of the problem only (identical on every rank)
     while True:
         rel = np.where(level == 2, np.float32(0), np.where(level == 1, np.float32(eps[1]), np.float32(eps[0]))).astype(np.float32)
-        img, cls, amb = engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps)
+        img, cls, amb = scan_bounded(probs, pred, ranks, rel, k, abs_eps)
         stats["scans"] += 1
         todo = np.flatnonzero(amb & (level < 2))
         moved = bound(0) > eps[0] or bound(1) > eps[1]

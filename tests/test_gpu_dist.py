@@ -47,6 +47,39 @@ gdist.barrier()
 '''
 
 
+TRAINER = r'''
+import os, sys, pickle, torch
+sys.path.insert(0, os.environ["GRIP_REPO"]); sys.path.insert(0, os.path.join(os.environ["GRIP_REPO"], "tests"))
+import grip_amd
+from grip_amd import dist as gdist
+from grip_amd.data import TensorPoolDataset
+from grip_amd.methods import TextualPrompt, VisualPrompt
+from grip_amd.methods.main import synthetic_pool
+from test_gpu_strategies import _conf
+rank, ws = gdist.init_from_env()
+out = {"ws": ws}
+classes, files, images, names = synthetic_pool(4, 24, 64, 3)          # 96 images: three steps of 32 per epoch
+l2i = {c: i for i, c in enumerate(classes)}
+for tag, cls, model in (("vpt", VisualPrompt, "visual_prompt"), ("coop", TextualPrompt, "textual_prompt")):
+    conf = _conf(MODEL=model, LEARNING_PARADIGM="ssl", EPOCHS=2, LR=0.05, BATCH_SIZE=32 // ws, GRAPH_STEPS=os.environ.get("GRIP_T_GRAPH", "1") == "1")
+    data = TensorPoolDataset(files, images.cuda(), labels=names, label_map=l2i)
+    m = cls(conf, l2i, classes, classes, classes, "cuda")
+    m.define_model(classes)
+    loader = m._loader(data, True)
+    stats = [m._train_epoch(loader) for _ in range(2)]
+    out[tag] = (m.unwrap_model().prefix.detach().cpu(), stats, len(loader), m.initial_prefix.reshape(m.unwrap_model().prefix.shape).clone())
+    # evaluation loops on a RAGGED pool (85 of the 96 images, batch 16 on every rank count): frame / validation accuracy / logits
+    m.config.BATCH_SIZE = 16
+    sub = TensorPoolDataset(files[:85], images[:85].cuda(), labels=names[:85], label_map=l2i)
+    df = m.test_predictions(sub)
+    ev = m.evaluation(sub)
+    out[tag + "_eval"] = (list(df["id"]), list(df["class"]), m._run_validation(sub), ev[0], ev[1], ev[2])
+with open(os.environ["GRIP_OUT"] + f".{rank}", "wb") as f:
+    pickle.dump(out, f)
+gdist.barrier()
+'''
+
+
 def _port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -81,6 +114,47 @@ def test_sharded_encode_allgather_matches_single_process(tmp_path):
     assert ref["ident"] == ref["exact"] and r0["ident"] == ref["exact"] and r1["ident"] == ref["exact"]
     assert r0["refined"][0] == r1["refined"][0] == r0["refined"][1] + r1["refined"][1] and ref["refined"][0] == ref["refined"][1]
     assert torch.allclose(r0["g"], torch.full((3,), 1.5)) and torch.allclose(r1["g"], torch.full((3,), 1.5))
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_trainer_is_data_parallel_like_accelerate(tmp_path, graph):
+    """TrainingStrategy under N ranks = the reference under `accelerate launch`: every rank takes its OWN batches of BATCH_SIZE
+    (dist.rank_batches), gradients are averaged -- so two ranks x batch 16 walk the same global batches of 32 as one rank x batch 32 (plain mean CE:
+    row weights 1/32) and end an epoch with the same prompts up to summation order; and the evaluation loops (test_predictions / evaluation /
+    _run_validation: sharded, gathered, padded duplicates dropped, textual_prompt.py:239, 285-294) return the single-process results on a ragged pool."""
+    import pickle
+    script = tmp_path / "trainer.py"
+    script.write_text(TRAINER)
+    env = dict(_env(tmp_path), GRIP_T_GRAPH=graph)
+    one = subprocess.run([sys.executable, str(script)], env=dict(env, GRIP_OUT=str(tmp_path / "single")), capture_output=True, text=True, timeout=900, cwd=tmp_path)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_port()), str(script)], env=env, capture_output=True, text=True, timeout=1200, cwd=tmp_path)
+    assert two.returncode == 0, two.stderr[-3000:]
+    ref = pickle.load(open(str(tmp_path / "single") + ".0", "rb"))
+    r0 = pickle.load(open(str(tmp_path / "out") + ".0", "rb"))
+    r1 = pickle.load(open(str(tmp_path / "out") + ".1", "rb"))
+    assert ref["ws"] == 1 and r0["ws"] == r1["ws"] == 2
+    for tag in ("vpt", "coop"):
+        p_ref, st_ref, nb_ref, p_init = ref[tag]
+        moved = float((p_ref - p_init).norm())
+        assert moved > 0.02 * float(p_init.norm())                       # (the six steps did move the prompt)
+        for r in (r0, r1):
+            p, st, nb, _ = r[tag]
+            assert nb == nb_ref == 3                                     # three optimizer steps per epoch either way
+            # same global batches, same mean gradient -- up to the f16 rounding of two half-batch backwards against one (the prompt gradients are
+            # accurate to a cosine of 0.999 against fp32 autograd: tests/test_gpu_backward.py), i.e. a few percent of the distance travelled
+            assert float((p - p_ref).norm()) <= 5e-2 * moved, (tag, float((p - p_ref).norm()), moved)
+            for (l, a), (l_ref, a_ref) in zip(st, st_ref):
+                assert abs(l - l_ref) <= 2e-3 * max(1.0, abs(l_ref)) and abs(a - a_ref) <= 2.01 / 96, (tag, st, st_ref)
+        assert torch.equal(r0[tag][0], r1[tag][0])                       # both ranks hold the same prompts, bit for bit
+        e_ref = ref[tag + "_eval"]
+        for r in (r0, r1):
+            e = r[tag + "_eval"]
+            assert e[0] == e_ref[0] and e[3] == e_ref[3] and len(e[0]) == 85      # the frame's ids / the evaluation's image list: dataset order, no duplicates
+            assert torch.allclose(e[5], e_ref[5], rtol=2e-3, atol=5e-2)              # logits (100 x cosine; the two runs hold prompts equal to ~1e-4)
+            agree = sum(a == b for a, b in zip(e[1], e_ref[1])) / 85
+            assert agree >= 0.97 and abs(e[2] - e_ref[2]) <= 0.03, (tag, agree, e[2], e_ref[2])
 
 
 def test_bench_two_ranks(tmp_path):
