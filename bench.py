@@ -551,6 +551,62 @@ def structured_pool_block(loop):
         torch.cuda.empty_cache()
 
 
+def stress_model_block(loop):
+    """The index guarantee on non-degenerate statistics, at the bench size: `clip.load(..., synthetic="stress")` -- outlier channels
+    (|x| ~ 200) in the vision residual stream and an f16 overflow on about a fifth of the images (weights.stress_state_dict) -- on the structured pool
+    with class prototypes as text features (peaked rows, contested arg-maxes).  Reported: identical-mode lists == exact-mode lists, rows per tier,
+    non-finite screen rows, bound and audit, pass rate.  Outside the timed region."""
+    from grip_amd import clip as gclip
+    a, dev = loop.args, loop.device
+    n, C, k = a.pool, a.classes, a.k
+    m, _ = gclip.load("ViT-B/16", device=dev, synthetic="stress")
+    twin = m.exact_twin()
+    g = torch.Generator(device=dev).manual_seed(777)
+    pool = torch.empty(n, 3, 224, 224, dtype=torch.float32, device=dev)
+    ramp = torch.linspace(-1.0, 1.0, 224, device=dev).view(1, 1, 1, -1)
+    for lo in range(0, n, 2048):
+        hi = min(lo + 2048, n)
+        pool[lo:hi] = torch.empty(hi - lo, 3, 224, 224, device=dev).normal_(generator=g) * 0.5 + torch.empty(hi - lo, 3, 1, 1, device=dev).normal_(generator=g) * 2.0 \
+            + ramp * torch.empty(hi - lo, 3, 1, 1, device=dev).normal_(generator=g)
+    paths = [f"pool/{i:08d}.jpg" for i in range(n)]
+    labels = list(range(C))
+    try:
+        with torch.no_grad():
+            e32 = torch.empty(n, 512, device=dev)
+            t0 = time.perf_counter()
+            twin.visual.tower.encode_chunks(pool, e32, 0, n, a.exact_chunk, streams=1)
+            torch.cuda.synchronize()
+            t_exact = time.perf_counter() - t0
+            en = e32 / e32.norm(dim=-1, keepdim=True)
+            anchors = torch.randperm(n, generator=g, device=dev)[:C]
+            txt = (en[anchors] - en.mean(0, keepdim=True) + 0.003 * torch.empty(C, 512, device=dev).normal_(generator=g)).contiguous()
+            _, p32, _, a32 = engine.cosine_head(e32, txt, 100.0)
+        p32h, a32h = p32.cpu().numpy(), a32.cpu().numpy()
+        want = pl.leaderboard(p32h, a32h, paths, labels, k)
+        lg = np.log(np.maximum(p32h, 1e-45))
+        mid = pl.mid_tower(m, n)
+        pl.identical_lists(m.visual.tower, twin.visual.tower, pool, txt, 100.0, paths, labels, k, chunk=a.chunk, exact_chunk=a.exact_chunk, visual_mid=mid, mid_chunk=a.exact_chunk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = pl.identical_lists(m.visual.tower, twin.visual.tower, pool, txt, 100.0, paths, labels, k, chunk=a.chunk, exact_chunk=a.exact_chunk, visual_mid=mid, mid_chunk=a.exact_chunk)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rs = pl.LAST_REFINE_STATS
+        return {"pool_images": n, "classes": C, "k": k, "lists_identical_to_exact_mode": (list(got[0]), list(got[1])) == (list(want[0]), list(want[1])),
+                "identical_images_per_sec": n / dt, "exact_mode_images_per_sec": n / t_exact,
+                "logit_spread_max_minus_median": float(np.mean(lg.max(1) - np.median(lg, 1))), "mean_top_probability": float(p32h.max(1).mean()),
+                "distinct_argmax_classes": int(len(np.unique(a32h))),
+                "nonfinite_screen_rows": rs["nonfinite_screen_rows"], "rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"],
+                "rows_reencoded_exactly": rs["rows_exact"], "tiers": rs["tiers"], "rounds": rs["rounds"], "relative_bound": rs["eps"],
+                "largest_deviation_seen": rs["max_deviation"], "relative_bound_split_f16": rs["eps_mid"], "audit_rows": rs["audit_rows"],
+                "audit_max_deviation": rs["audit_max_deviation"], "audit_widened_the_bound": rs["audit_widened"], "unverified_rows": rs["unverified_rows"],
+                "model": "ViT-B/16 synthetic-stress: ln_pre gain x 60 on 4 channels (|x| ~ 200 in the residual stream, LayerNorm gains compensated), last block scaled so "
+                         "that one stream channel of the CLS row leaves the f16 range on ~ 1/5 of the images; text features = mean-removed prototypes of the pool's own embeddings"}
+    finally:
+        del pool
+        torch.cuda.empty_cache()
+
+
 def from_files_block(loop, n=1536, chunk=384, procs=None, slots=1):
     """SURVEY.md 8f-2 (the reference's data/dataset.py:56-89 + utils/clip_pseudolabels.py:31-33: PIL open + transform per image on
     the host): images/sec from JPEG FILES to embeddings -- parallel decode on the host (threads, and worker processes around a
@@ -864,6 +920,11 @@ def main():
                 out["config"]["headline_pool_note"] = ("i.i.d. N(0,1) images (SURVEY 8d): a random-init tower gives nearly every image the same arg-max; "
                                                        "`structured_pool_identical_pass_images_per_sec` is the pseudolabel pass (no prompt steps) on a class-structured pool, "
                                                        "to be compared with `identical_images_per_sec`")
+            if args.mode == "identical":
+                try:
+                    out["secondary"]["identical_on_stress_model"] = stress_model_block(loop)
+                except Exception as e:
+                    out["secondary"]["identical_on_stress_model"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 out["secondary"]["from_files"] = from_files_block(loop)
             except Exception as e:      # the input pipeline is a NEXT row: its failure must not take the bench line down

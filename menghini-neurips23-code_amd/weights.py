@@ -106,41 +106,45 @@ def init_state_dict(d: ClipDims, seed: int = 0, logit_scale: float = math.log(10
 
 
 STRESS_OUTLIER_CHANNELS = (5, 77, 300, 511)     # (taken modulo the vision width)
-STRESS_OVERFLOW_GAIN = 2.0e4                    # on one output row of the last c_proj: the CLS value of that channel is ~ N(0, (5e4)^2) at ViT-B/16 (a fifth of the images beyond 65 504)
+STRESS_OVERFLOW_GAIN = (100.0, 800.0)           # (last block ln_2 gain, one c_proj output row): that CLS stream channel is ~ N(0, (5e4)^2) at ViT-B/16, a fifth of the images beyond 65 504
 
 
-def stress_state_dict(d: ClipDims, seed: int = 0):
+def stress_state_dict(d: ClipDims, seed: int = 0, outlier: float = 200.0, overflow_gain=None, channels=None):
     """The synthetic weights of init_state_dict bent towards what trained CLIP checkpoints do to low-precision arithmetic and the seeded random init does
-    not: (a) MASSIVE ACTIVATIONS -- four channels of the vision residual stream carry |x| ~ 200 (ln_pre gain x 60), so every later
-    LayerNorm is dominated by them and the f16 towers' relative error grows; (b) an F16 OVERFLOW that depends on the image -- one output channel of the
-    last block's c_proj is scaled until the CLS row leaves the f16 range (> 65 504) for roughly a fifth of the images: their f16 embeddings are
-    non-finite (the `nonfinite_screen_rows` path of pseudolabels.refine_scan through the REAL towers), while the f32 / split-f16 towers, whose stream is
-    f32, stay finite.  Everything else is the standard init; the text tower is untouched.  Test / bench model only (`clip.load(..., synthetic="stress")`)."""
+    not: (a) MASSIVE ACTIVATIONS -- four channels of the vision residual stream sit at x ~ +200 on every token (an ln_pre bias, as the
+    near-constant outlier channels of trained ViTs are), so the row mean is ~ 1 and the row variance ~ 200 in every later LayerNorm, which stresses the
+    statistics, the LayerNorm-folded GEMMs' `acc - mean * colsum` and the f16 stream's 0.125 ulp at 200; as trained models do, the LayerNorms that READ
+    the stream carry small gains on those channels and correspondingly larger ones elsewhere, so the blocks compute on inputs of the usual scale.
+    (Outliers whose magnitude varies from token to token -- a GAIN on ln_pre instead of a bias -- make the network ill-conditioned in fp32 itself:
+    oracle/gen_golden_stress.py measures fp32 against fp64, 3e-2 in cosine for that variant, 2e-7 for this one.)  (b) an F16 OVERFLOW that depends on the
+    image -- the last block's ln_2 gain and one output row of its c_proj are scaled until that stream channel of the CLS row leaves the f16 range
+    (> 65 504) for roughly a fifth of the images: their f16 embeddings are non-finite (the `nonfinite_screen_rows` path of pseudolabels.refine_scan
+    through the REAL towers) while the f32 / split-f16 towers, whose stream is f32, stay finite; the channel does not reach the embedding (ln_post gain
+    0).  Every GEMM operand stays far inside the f16 range.  The text tower is untouched.  Test / bench model (`clip.load(..., synthetic="stress")`)."""
     sd = init_state_dict(d, seed)
     vw = d.vision_width
-    ch = sorted({c % vw for c in STRESS_OUTLIER_CHANNELS})
+    overflow_gain = STRESS_OVERFLOW_GAIN if overflow_gain is None else overflow_gain
+    ch = sorted({c % vw for c in (STRESS_OUTLIER_CHANNELS if channels is None else channels)})
     rest = np.ones(vw, dtype=bool)
     rest[ch] = False
-    g = sd["visual.ln_pre.weight"].copy()
-    g[ch] *= 60.0
-    sd["visual.ln_pre.weight"] = g
-    # The LayerNorms that READ the stream see a variance dominated by the outliers, so the ordinary channels come out ~ 1 / (200 sqrt(4 / vw)) too
-    # small: as trained models do, give those LayerNorms small gains on the outlier channels and correspondingly larger ones elsewhere -- the blocks
-    # then compute on inputs of the usual scale while the stream keeps carrying |x| ~ 200 through every layer (LN statistics, the LN-folded GEMMs'
-    # mean * colsum cancellation and the f16 stream's 0.125 ulp at 200 are what this stresses).
-    lift = np.float32(200.0 * math.sqrt(len(ch) / vw))
-    for key in [k for k in sd if k.startswith("visual.") and (k.endswith("ln_1.weight") or k.endswith("ln_2.weight") or k == "visual.ln_post.weight")]:
-        g = sd[key].copy()
-        g[ch] /= 60.0
-        g[rest] *= lift
-        sd[key] = g
-    last = f"visual.transformer.resblocks.{d.vision_layers - 1}.mlp.c_proj.weight"
-    w = sd[last].copy()
-    row = (ch[0] + 1) % vw
-    w[row] *= np.float32(STRESS_OVERFLOW_GAIN)
-    sd[last] = w
+    if ch and outlier:
+        b = sd["visual.ln_pre.bias"].copy()
+        b[ch] += np.float32(outlier)
+        sd["visual.ln_pre.bias"] = b
+        std = math.sqrt(1.0 + len(ch) * outlier * outlier / vw)        # what a row's standard deviation becomes
+        for key in [k for k in sd if k.startswith("visual.") and (k.endswith("ln_1.weight") or k.endswith("ln_2.weight") or k == "visual.ln_post.weight")]:
+            g = sd[key].copy()
+            g[ch] *= np.float32(1.0 / outlier)
+            g[rest] *= np.float32(std)
+            sd[key] = g
+    blk = f"visual.transformer.resblocks.{d.vision_layers - 1}"
+    sd[blk + ".ln_2.weight"] = sd[blk + ".ln_2.weight"] * np.float32(overflow_gain[0])
+    w = sd[blk + ".mlp.c_proj.weight"].copy()
+    row = (ch[0] + 1) % vw if ch else 6
+    w[row] *= np.float32(overflow_gain[1])
+    sd[blk + ".mlp.c_proj.weight"] = w
     g = sd["visual.ln_post.weight"].copy()
-    g[row] = 0.0            # the overflowing channel does not reach the embedding (in f32); in the f16 stream it is inf for the rows it overflows on
+    g[row] = 0.0
     sd["visual.ln_post.weight"] = g
     return sd
 

@@ -226,9 +226,37 @@ def run_case(group, case, out):
     out[f"{tag}.margin"] = np.float64(margin)
 
 
+# Un-selected seeds: the CASES above were chosen for a decision margin >= 7e-5; these are simply the next ten pool / prompt seeds of each
+# modality, whatever their margin -- tests/test_gpu_assign.py reports how many of them come out list-identical and checks what must hold for all.
+UNSELECTED = {
+    "small": [(m, rel, pkg, base, cls, 6, 40, 1000 + 10 * j + i, k, 4, 2000 + 10 * j + i)
+              for j, (m, rel, pkg, base, cls, _a, _b, _c, k, _d, _e) in enumerate(CASES["small"]) for i in range(10)],
+    "vitb16": [(m, rel, pkg, base, cls, 5, 14, 3000 + 10 * j + i, k, P, 4000 + 10 * j + i)
+               for j, (m, rel, pkg, base, cls, _a, _b, _c, k, P, _e) in enumerate(CASES["vitb16"]) for i in range(10)],
+}
+
+
+def main_unselected(group):
+    """python oracle/gen_golden_assign.py unselected-small | unselected-vitb16   -> tests/golden/assign_unselected_{group}.npz"""
+    keep = ("meta", "probs", "pred", "margin", "coop", "vpt", "prefix")
+    out = {}
+    for case in UNSELECTED[group]:
+        one = {}
+        run_case(group, case, one)
+        for key, v in one.items():
+            tag, what = key.split(".", 1)
+            if what in keep:
+                out[f"{tag}.{case[7]}.{what}"] = v
+    path = os.path.join(REPO, "tests", "golden", f"assign_unselected_{group}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
 def main():
     """python oracle/gen_golden_assign.py [small] [vitb16]   (no argument = both)"""
     torch.manual_seed(0)
+    if len(sys.argv) == 2 and sys.argv[1].startswith("unselected-"):
+        return main_unselected(sys.argv[1].split("-", 1)[1])
     groups = sys.argv[1:] or ["small", "vitb16"]
     for group in groups:
         out = {}
