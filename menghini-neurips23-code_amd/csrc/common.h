@@ -193,6 +193,8 @@ struct GemmArgs {
     // column panel says).  Changes the summation order with the tile row, so only train-mode launches may set it (the inference
     // forwards stay bit-identical under any chunking).
     int rot_rows;
+    int ablate;         // developer builds only (-DGRIP_ABLATE, tools/mlp_ablation.sh): bit 0 = the c_fc epilogue issues no global store, bit 1 = the K = 4 d
+                        // residual GEMM reads its A operand from a 31-MB window (Infinity-Cache resident); timing experiments, results are wrong by design
 };
 int gemm_pick_ksplit(int M, int N, int K);
 int gemm_pick_coop_split(int M, int N, int K);   // split factor of the cooperative form (1 = not worth it / not applicable)

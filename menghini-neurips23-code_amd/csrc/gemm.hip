@@ -529,6 +529,21 @@ __device__ __forceinline__ void epilogue_direct_impl(const GemmArgs& g, f32x4 (&
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = quick_gelu4(v[j]);
             }
+#ifdef GRIP_ABLATE
+            if (g.ablate & 4) {         // the stores are issued, but into a 5 120-row window (31 MB: they never have to leave the Infinity Cache)
+                const uint32_t ow = (uint32_t)(row % 5120) * (uint32_t)ldc + (uint32_t)col;
+                *(half8*)((half_t*)g.out + ow) = pack8(v[0], v[1]);
+                *(half8*)((half_t*)g.out + ow + 8) = pack8(v[2], v[3]);
+                continue;
+            }
+            if (g.ablate & 1) {         // everything but the store (the values stay live: they are stored when the row index is impossible)
+                if (row == 0x7fffffff) {
+                    *(half8*)((half_t*)g.out + o) = pack8(v[0], v[1]);
+                    *(half8*)((half_t*)g.out + o + 8) = pack8(v[2], v[3]);
+                }
+                continue;
+            }
+#endif
             *(half8*)((half_t*)g.out + o) = pack8(v[0], v[1]);
             *(half8*)((half_t*)g.out + o + 8) = pack8(v[2], v[3]);
         }
@@ -1527,6 +1542,9 @@ __global__ __launch_bounds__(512) void gemm_k64p_kernel(GemmArgs g, int tiles_m,
     auto tile_src = [&](int tile) {         // uniform: first staged row of this wave in the tile's A or W panel
         int tm, tn;
         tile_coords(tile, tm, tn);
+#ifdef GRIP_ABLATE
+        if ((g.ablate & 2) && g.K >= 2048 && r0 < BMT) tm %= 20;       // A from a 20-panel window (5 120 rows x 6 KB = 31 MB: Infinity-Cache resident)
+#endif
         return r0 < BMT ? (const half_t*)g.A + (size_t)(tm * BMT + r0) * K : (const half_t*)g.W + (size_t)(tn * BNT + r0 - BMT) * K;
     };
     auto stage = [&](int buf, const half_t* src, int kt) {
@@ -1864,7 +1882,15 @@ static int launch_k64w(int epi, const GemmArgs& a, hipStream_t s) {
     return GRIP_OK;
 }
 
-static int launch_k64p(int epi, const GemmArgs& a, hipStream_t s) {
+#ifdef GRIP_ABLATE
+static int g_ablate = 0;
+extern "C" int grip_debug_ablate(int mask) { g_ablate = mask; return GRIP_OK; }
+#endif
+static int launch_k64p(int epi, const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+#ifdef GRIP_ABLATE
+    a.ablate = g_ablate;
+#endif
     const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
     constexpr size_t lds = (size_t)2 * 512 * BK * 2 + 8 * 4096;       // two stages + eight 4 KiB slabs = the whole 160 KiB
     static int n_cu = 0;
