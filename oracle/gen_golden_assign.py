@@ -232,7 +232,7 @@ UNSELECTED = {
     "small": [(m, rel, pkg, base, cls, 6, 40, 1000 + 10 * j + i, k, 4, 2000 + 10 * j + i)
               for j, (m, rel, pkg, base, cls, _a, _b, _c, k, _d, _e) in enumerate(CASES["small"]) for i in range(10)],
     "vitb16": [(m, rel, pkg, base, cls, 5, 14, 3000 + 10 * j + i, k, P, 4000 + 10 * j + i)
-               for j, (m, rel, pkg, base, cls, _a, _b, _c, k, P, _e) in enumerate(CASES["vitb16"]) for i in range(10)],
+               for j, (m, rel, pkg, base, cls, _a, _b, _c, k, P, _e) in enumerate(CASES["vitb16"]) for i in range(4)],     # (four per modality: a case is 15 - 80 CPU-seconds)
 }
 
 

@@ -141,7 +141,7 @@ class _Sub:
 @pytest.mark.parametrize("group", ["small", "vitb16"])
 @pytest.mark.parametrize("modality", ["multi", "text", "image"])
 def test_unselected_seeds(tmp_path, monkeypatch, group, modality):
-    """the fixtures above were SELECTED for a decision margin >= 7e-5.  These are the next ten pool / prompt seeds per modality, whatever
+    """the fixtures above were SELECTED for a decision margin >= 7e-5.  These are the next ten (ViT-B/16: four) pool / prompt seeds per modality, whatever
     their margin (oracle/gen_golden_assign.py unselected-<group>: the reference's own assign_pseudo_labels, margins down to 3e-7 relative).  What must
     hold for every one of them: the same number of pairs per class, and lists identical to the reference's whenever its decision margin is above
     the fp32 GPU-vs-CPU deviation of the probabilities (PROB_TOL); below it -- the reference's own outcome then hangs on the last bits of its
@@ -152,7 +152,7 @@ def test_unselected_seeds(tmp_path, monkeypatch, group, modality):
         pytest.skip(f"{path} not generated")
     fx = np.load(path)
     seeds = sorted({int(k.split(".")[1]) for k in fx.files if k.startswith(modality + ".") and k.endswith(".meta")})
-    assert len(seeds) == 10
+    assert len(seeds) == (10 if group == "small" else 4)
     identical = same_set = 0
     report = []
     for seed in seeds:
@@ -174,4 +174,4 @@ def test_unselected_seeds(tmp_path, monkeypatch, group, modality):
             assert overlap >= 0.9, (seed, overlap)
         del m
         torch.cuda.empty_cache()
-    print(f"{group}.{modality}: {identical} of 10 un-selected seeds list-identical, {same_set} with the same pair set; " + "; ".join(report))
+    print(f"{group}.{modality}: {identical} of {len(seeds)} un-selected seeds list-identical, {same_set} with the same pair set; " + "; ".join(report))
