@@ -38,7 +38,7 @@ typedef enum {
 const char* grip_last_error(void);
 /* ABI version of this header; the host layer refuses a library that reports another one. */
 int grip_abi_version(void);
-#define GRIP_ABI_VERSION 6
+#define GRIP_ABI_VERSION 7
 
 /* ------------------------------------------------------------------------------------------
  * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
@@ -294,6 +294,15 @@ int grip_bpe_destroy(grip_bpe* t);
 int grip_bpe_special_ids(const grip_bpe* t, int32_t* sot, int32_t* eot, int32_t* vocab_size);
 int grip_bpe_encode_word(grip_bpe* t, const uint8_t* word, int n, int32_t* ids, int cap, int* n_out);
 int grip_bpe_encode_ascii(grip_bpe* t, const char* text, int n, int32_t* ids, int cap, int* n_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch width of the persistent kernels (ABI 7).  The pool-encode GEMMs and the pipelined attention size their grids to the WHOLE chip (one
+ * workgroup per CU, each walking many tiles).  A host that runs an encode on a CU-masked stream (hipExtStreamCreateWithCUMask) next to other work --
+ * the frozen image tower's look-ahead encode of a textual-prompt epoch beside the latency-bound prompt steps, textual_prompt.py:95-103 -- tells the
+ * library how many CUs that stream owns, so that the persistent grids fit them (a 256-workgroup grid on 192 CUs would run in two rounds).
+ * n_cus = 0 restores the full width.  Process-wide host state read at launch time: set it around the launches it is meant for.  Results do not
+ * depend on it (tile -> workgroup assignment never changes an element's arithmetic). */
+int grip_set_cu_budget(int n_cus);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU exchange (one process per GPU, RCCL over the xGMI mesh).  The unlabeled pool shards contiguously over the

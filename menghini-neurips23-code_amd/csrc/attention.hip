@@ -304,7 +304,7 @@ template <int KVC, int NW>
 static int launch_pipe(const half_t* qkv, half_t* out, int B, int S, int H, hipStream_t s) {
     constexpr int SP = KVC * 32;
     constexpr size_t lds = 2 * ((size_t)2 * SP * 64 * 2);
-    static int resident = 0;     // workgroups the device holds at once (LDS- or register-limited), = the persistent grid
+    static int resident = 0, per_cu_s = 0;     // workgroups the device holds at once (LDS- or register-limited), = the persistent grid
     if (!resident) {
         GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<KVC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0, n_cu = 0, per_cu = 0;
@@ -313,9 +313,11 @@ static int launch_pipe(const half_t* qkv, half_t* out, int B, int S, int H, hipS
         GRIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_fwd_pipe_kernel<KVC, NW>, NW * 64, lds));
         GRIP_REQUIRE(per_cu >= 1, "attention: pipelined kernel does not fit a CU (KVC %d)", KVC);
         resident = n_cu * per_cu;
+        per_cu_s = per_cu;
     }
     const int n_items = B * H;
-    const int grid = n_items < resident ? n_items : resident;
+    const int width = (grip_cu_budget() > 0 && grip_cu_budget() * per_cu_s < resident) ? grip_cu_budget() * per_cu_s : resident;     // a CU-masked launch stream
+    const int grid = n_items < width ? n_items : width;
     static const int dbg = getenv("GRIP_ATTN_DBG") ? atoi(getenv("GRIP_ATTN_DBG")) : 0;     // developer experiments (bit 0: skip the output stores)
     hipLaunchKernelGGL((attn_fwd_pipe_kernel<KVC, NW>), dim3(grid), dim3(NW * 64), lds, s, qkv, out, S, H, n_items, dbg);
     GRIP_CHECK_HIP(hipGetLastError());

@@ -30,6 +30,8 @@ typedef half_t resid_t;
         }                                                                                      \
     } while (0)
 
+int grip_cu_budget();      // grip_set_cu_budget (tower.hip): CUs the persistent kernels may size their grids to, 0 = all
+
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ---------------------------------------------------------------------------------------------

@@ -1893,14 +1893,16 @@ static int launch_k64p(int epi, const GemmArgs& a_in, hipStream_t s) {
 #endif
     const int tiles_m = (a.M + 255) / 256, tiles_n = a.N / 256;
     constexpr size_t lds = (size_t)2 * 512 * BK * 2 + 8 * 4096;       // two stages + eight 4 KiB slabs = the whole 160 KiB
-    static int n_cu = 0;
-    if (!n_cu) {
+    static int n_cu_dev = 0;
+    if (!n_cu_dev) {
         int dev = 0;
         GRIP_CHECK_HIP(hipGetDevice(&dev));
-        GRIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu &= ~7;
-        GRIP_REQUIRE(n_cu >= 8, "gemm: device reports %d CUs", n_cu);
+        GRIP_CHECK_HIP(hipDeviceGetAttribute(&n_cu_dev, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu_dev &= ~7;
+        GRIP_REQUIRE(n_cu_dev >= 8, "gemm: device reports %d CUs", n_cu_dev);
     }
+    int n_cu = n_cu_dev;
+    if (grip_cu_budget() > 0 && grip_cu_budget() < n_cu_dev) n_cu = grip_cu_budget() & ~7;     // the launch stream owns fewer CUs (grip_set_cu_budget)
     const int tiles = tiles_m * tiles_n;
     // every XCD owns ceil or floor(tiles_m / 8) row panels: the grid has enough workgroups per XCD for the largest band
     const int band = ((tiles_m + 7) / 8) * tiles_n;

@@ -28,6 +28,14 @@ void grip_set_error(const char* fmt, ...) {
 extern "C" const char* grip_last_error(void) { return g_err; }
 extern "C" int grip_abi_version(void) { return GRIP_ABI_VERSION; }
 
+static int g_cu_budget = 0;
+int grip_cu_budget() { return g_cu_budget; }
+extern "C" int grip_set_cu_budget(int n_cus) {
+    GRIP_REQUIRE(n_cus >= 0 && (n_cus == 0 || n_cus >= 8), "set_cu_budget: %d (0 = all, else at least 8)", n_cus);
+    g_cu_budget = n_cus;
+    return GRIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- layout
 struct LayerW {
     // f16 (element offsets into the f16 blob)

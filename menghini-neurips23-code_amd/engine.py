@@ -530,3 +530,45 @@ def leaderboard_scan_bounded(probs, pred, path_rank, rel_eps, k, abs_eps=0.0):
                                                    c_void_p(eps.ctypes.data), float(abs_eps), n, c, int(k), c_void_p(out_img.ctypes.data),
                                                    c_void_p(out_cls.ctypes.data), byref(m), c_void_p(amb.ctypes.data), byref(na)))
     return out_img[: m.value].copy(), out_cls[: m.value].copy(), amb[:n].astype(bool)
+
+
+# ------------------------------------------------------------------------------------------ CU-masked side stream (look-ahead encodes)
+_MASKED_STREAMS = {}
+
+
+def set_cu_budget(n_cus):
+    """grip_set_cu_budget: CUs the persistent kernels may size their grids to for the launches that follow (0 = the whole chip)."""
+    native.check(native.lib().grip_set_cu_budget(int(n_cus)))
+
+
+def masked_stream(device, quarters=3):
+    """(torch stream, n_cus) whose kernels may only run on `quarters` / 4 of the chip's CUs (hipExtStreamCreateWithCUMask), or None when the runtime
+    refuses.  Every 32-CU XCD and every 8-CU slice of the CU numbering loses the same share whichever way the driver numbers the CUs (CU i is dropped
+    when (i / 8 + i) % 4 >= quarters), so the XCD-aware tile walks of the GEMMs stay balanced.  What it is for: a throughput-bound encode on most of
+    the chip next to a latency-bound chain of small kernels on the rest (steps.lookahead_image_features)."""
+    import ctypes
+    import os
+    dev = torch.device(device)
+    key = (dev.index or 0, quarters)
+    if key in _MASKED_STREAMS:
+        return _MASKED_STREAMS[key]
+    out = None
+    try:
+        total = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (total + 31) // 32
+        mask = (ctypes.c_uint32 * words)()
+        kept = 0
+        for i in range(total):
+            if (i // 8 + i) % 4 < quarters:
+                mask[i // 32] |= 1 << (i % 32)
+                kept += 1
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        st = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+        if rc == 0 and st.value:
+            out = (torch.cuda.ExternalStream(st.value, device=dev), kept)
+    except Exception:
+        out = None
+    _MASKED_STREAMS[key] = out
+    return out

@@ -104,8 +104,8 @@ def leaderboard(probs, pred, paths, class_labels, k):
 # ------------------------------------------------------------------------------------------ screen and refine
 REFINE_CALIB_ROWS = 256     # rows re-encoded exactly up front to measure the cheaper tiers' deviation on THIS pool
 REFINE_SAFETY = 2.0         # bound = safety x the largest deviation seen on any row re-encoded so far (it only ever grows)
-REFINE_SAFETY_MID = 8.0     # the same for the middle tier: its bound rests on a quarter of the calibration rows (an f32 row costs 2.5 split-f16 ones), so it is
-                            # given four times the margin instead -- at 1e-5-sized deviations the extra band holds a handful of rows
+REFINE_SAFETY_MID = 4.0     # the same for the middle tier: its bound rests on a quarter of the calibration rows (an f32 row costs 2.5 split-f16 ones), so it is
+                            # given twice the margin instead (8 x was measured: 293 instead of 222 f32 rows per pass on the bench pool, +0.025 s) -- at 1e-5-sized deviations the extra band holds a handful of rows
 REFINE_ESCALATE_AFTER = 8   # rounds after which whatever is still un-refined moves up a tier in one go (pathological pools only, see refine_scan)
 REFINE_AUDIT_ROWS = 256     # un-refined rows re-encoded AFTER the scan certified its lists, to check the bound they were trusted to ($GRIP_REFINE_AUDIT)
 REFINE_MAX_AUDITS = 4       # audits that may each widen the bound before everything left is simply re-encoded

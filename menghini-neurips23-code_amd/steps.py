@@ -225,33 +225,84 @@ class GraphedCoopFeatureStep(GraphedStep):
         return coop_step(self.model, self.clip_model, None, labels, row_weight, self.optimizer, image_features=feats, return_logits=True)
 
 
-def lookahead_image_features(clip_model, batches, group=8):
+def lookahead_overlap():
+    """Quarters of the chip an overlapped look-ahead encode may use (1-3), 0 = no overlap (the default).  $GRIP_LOOKAHEAD_OVERLAP (developer A/B: measured
+    and rejected in r05 -- on this runtime the masked stream's kernels and the graph replays of the steps do not run side by side)."""
+    import os
+    v = os.environ.get("GRIP_LOOKAHEAD_OVERLAP", "0")
+    return int(v) if v in ("0", "1", "2", "3") else 0
+
+
+def lookahead_image_features(clip_model, batches, group=8, overlap=None):
     """The frozen image tower of a textual-prompt epoch, run `group` batches ahead: the image features of a step do not depend
     on the prompt being trained, so the batches of `group` consecutive steps are encoded in ONE inference forward (group x B x S
     rows feed the persistent 256x256 GEMMs at the pool-encode rate; a 16-image forward leaves them a quarter full) and each
     step receives its slice.  Every image is still encoded every time a step uses it (nothing is cached across steps or epochs),
     and the engine's forward is chunk-independent, so the features are bit-identical to a per-step encode.
 
+    r05 experiment, OFF by default (`overlap` / GRIP_LOOKAHEAD_OVERLAP = 1..3 quarters of the chip): the encode of group g + 1 enqueued on a CU-masked
+    side stream (engine.masked_stream; the persistent kernels size their grids to it, grip_set_cu_budget) BEFORE group g's features are yielded, so that
+    it could run beside the prompt steps -- a latency-bound chain of ~176 launches of 28 - 60 workgroups each -- on the CUs the mask leaves free.  Same
+    features bit for bit (tests/test_gpu_determinism.py), but no overlap happens on this runtime: encode 28.5 ms + 51 steps 56.3 ms take 102 ms
+    "together" (88 ms with an ordinary side stream), tools/overlap_probe.py; DESIGN 8.6.
+
     `batches` yields tuples whose first element is the image batch [B, 3, R, R] (any further elements are passed through);
     yields (features [B, embed_dim], *rest) in the same order."""
-    pending = []
+    quarters = lookahead_overlap() if overlap is None else int(overlap)
 
-    def flush():
+    def groups():
+        pending = []
+        for b in batches:
+            pending.append(b)
+            if len(pending) == group:
+                yield pending
+                pending = []
+        if pending:
+            yield pending
+
+    def encode(pending, side=None, budget=0):
+        x = torch.cat([b[0] for b in pending])
         with torch.no_grad():
-            feats = clip_model.encode_image(torch.cat([b[0] for b in pending]))
+            if side is None:
+                return clip_model.encode_image(x)
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                engine.set_cu_budget(budget)
+                try:
+                    feats = clip_model.encode_image(x)
+                finally:
+                    engine.set_cu_budget(0)
+            x.record_stream(side)
+            return feats
+
+    def slices(pending, feats):
         at = 0
         for b in pending:
             n = b[0].shape[0]
             yield (feats[at:at + n],) + tuple(b[1:])
             at += n
-        pending.clear()
 
-    for b in batches:
-        pending.append(b)
-        if len(pending) == group:
-            yield from flush()
-    if pending:
-        yield from flush()
+    it = groups()
+    cur = next(it, None)
+    if cur is None:
+        return
+    ms = engine.masked_stream(cur[0][0].device, quarters) if quarters and cur[0][0].is_cuda else None
+    if ms is None:
+        while cur is not None:
+            yield from slices(cur, encode(cur))
+            cur = next(it, None)
+        return
+    side, n_cus = ms
+    feats = encode(cur)
+    while cur is not None:
+        nxt = next(it, None)
+        nxt_feats = encode(nxt, side, n_cus) if nxt is not None else None      # enqueued BEFORE this group's steps: runs beside them
+        yield from slices(cur, feats)
+        if nxt is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            nxt_feats.record_stream(torch.cuda.current_stream())
+        cur, feats = nxt, nxt_feats
 
 
 class GraphedVptStep(GraphedStep):

@@ -102,3 +102,29 @@ def test_pool_encode_is_bitwise_independent_of_the_chunking():
         outs.append(o.clone())
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+
+
+def test_overlapped_lookahead_encode_is_bitwise_the_sequential_one():
+    """r05: steps.lookahead_image_features encodes group g + 1 on a CU-masked side stream (three quarters of the chip, persistent grids sized by
+    grip_set_cu_budget) while the steps of group g run.  The launch width changes which workgroup computes a tile, never an element's arithmetic:
+    overlapped == sequential == one encode per batch, bit for bit -- with concurrent work on the main stream in between, as in a real epoch."""
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, engine, steps
+    m, _ = clip.load("ViT-B/16", device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    batches = [(torch.randn(16, 3, 224, 224, device="cuda", generator=g), i) for i in range(28)]      # 28 batches: groups of 12, 12 and a ragged 4
+    with torch.no_grad():
+        want = [m.encode_image(x) for x, _ in batches]
+    junk = torch.randn(2048, 2048, device="cuda")
+    for overlap in (3, 2, 0):
+        got = []
+        for f, i in steps.lookahead_image_features(m, iter(batches), 12, overlap=overlap):
+            for _ in range(4):
+                junk = junk @ junk * 1e-3              # the "prompt step" of this batch: main-stream work beside the side stream's encode
+            got.append((f.clone(), i))
+        torch.cuda.synchronize()
+        assert [i for _, i in got] == list(range(28))
+        for (f, _), w in zip(got, want):
+            assert torch.equal(f, w), overlap
+    if engine.masked_stream("cuda", 3) is None:
+        pytest.skip("hipExtStreamCreateWithCUMask refused: only the sequential form ran")

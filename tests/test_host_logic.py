@@ -295,3 +295,24 @@ def test_cooperative_split_factor_choice():
     assert f(425, 512, 512) == 1           # 8 slices: nothing to split
     assert f(3408, 768, 3072) == 1         # the image tower's prompt step
     assert f(425, 500, 2048) == 1          # N % 128 != 0
+
+
+def test_lookahead_image_features_groups_and_order():
+    """steps.lookahead_image_features on the host path (no GPU: the sequential form): every batch comes back once, in order, with its own slice of the
+    group's features and its pass-through elements, for groups that do and do not divide the batch count and a ragged last batch."""
+    import types
+    import torch
+    import grip_amd  # noqa: F401
+    from grip_amd import steps
+    calls = []
+    model = types.SimpleNamespace(encode_image=lambda x: (calls.append(len(x)), x.reshape(len(x), -1)[:, :3] * 2.0)[1])
+    sizes = [4, 4, 4, 4, 4, 4, 3]
+    data = [(torch.full((n, 1, 2, 2), float(i)), i, f"b{i}") for i, n in enumerate(sizes)]
+    for group in (1, 2, 3, 7, 50):
+        calls.clear()
+        got = list(steps.lookahead_image_features(model, iter(data), group))
+        assert [g[1:] for g in got] == [(i, f"b{i}") for i in range(len(sizes))]
+        for (f, i, _), n in zip(got, sizes):
+            assert f.shape == (n, 3) and torch.all(f == 2.0 * i)
+        assert sum(calls) == sum(sizes) and len(calls) == -(-len(sizes) // group)
+    assert list(steps.lookahead_image_features(model, iter([]), 4)) == []

@@ -2,7 +2,7 @@
 # Final collection of a round (TAG=r05a): whole GPU suite, rocprofv3 kernel stats + PMC passes + the default bench line, in-situ kernel tables of the three
 # prompt steps (eager loops under rocprofv3), the graphed CoOp step (replay time + per-kernel table of one replay), SQ counters of the VPT step's kernels
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-T=${TAG:-r05}
+T=${TAG:-r05a}
 mkdir -p $R/gpurun_out
 cd $R
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|rror|FAILED|ERROR" | tail -8 > $R/gpurun_out/gputest_$T.log
