@@ -1,0 +1,65 @@
+"""Developer probe (r05): what does a dependent kernel cost inside a HIP-graph replay on this box, as a function of what the kernel is?
+Chains of N dependent launches captured once and replayed: (a) a trivial torch elementwise kernel on 1 element, (b) on 1 M elements,
+(c) the library's smallest LayerNorm (425 x 512), (d) its 64 x 128 loader-wave GEMM at K = 512 (425 x 512 x 512)."""
+import ctypes
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import grip_amd  # noqa: E402,F401
+from grip_amd import native  # noqa: E402
+
+dev = torch.device("cuda", 0)
+lib = native.lib()
+N = 200
+
+
+def replay_us(body):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(N):
+            body()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        t = time.perf_counter()
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t) / 10)
+    return best / N * 1e6
+
+
+a1 = torch.zeros(1, device=dev)
+am = torch.zeros(1 << 20, device=dev)
+print(f"torch add_ on 1 element:        {replay_us(lambda: a1.add_(1.0)):.2f} us per dependent launch")
+print(f"torch add_ on 1 M elements:     {replay_us(lambda: am.add_(1.0)):.2f} us")
+x = torch.randn(512, 512, device=dev)
+g_ = torch.ones(512, device=dev)
+b_ = torch.zeros(512, device=dev)
+o = torch.empty(512, 512, dtype=torch.float16, device=dev)
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+print(f"library LayerNorm 425 x 512:    {replay_us(lambda: native.check(lib.grip_debug_layernorm(p(x), p(g_), p(b_), p(o), 425, 512, st()))):.2f} us")
+A = torch.randn(512, 512, device=dev).half()
+W = torch.randn(512, 512, device=dev).half()
+C = torch.empty(512, 512, dtype=torch.float16, device=dev)
+C2 = torch.empty(512, 512, dtype=torch.float16, device=dev)
+
+
+def gemm_pair():
+    native.check(lib.grip_debug_gemm(4, p(A), p(W), 425, 512, 512, None, None, None, p(C), None, ctypes.c_float(1.0), 512, 0, st()))
+    native.check(lib.grip_debug_gemm(4, p(C), p(W), 425, 512, 512, None, None, None, p(C2), None, ctypes.c_float(1.0), 512, 0, st()))
+
+
+print(f"library GEMM 425 x 512 x 512:   {replay_us(gemm_pair) / 2:.2f} us")
