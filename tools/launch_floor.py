@@ -62,4 +62,16 @@ def gemm_pair():
     native.check(lib.grip_debug_gemm(4, p(C), p(W), 425, 512, 512, None, None, None, p(C2), None, ctypes.c_float(1.0), 512, 0, st()))
 
 
-print(f"library GEMM 425 x 512 x 512:   {replay_us(gemm_pair) / 2:.2f} us")
+print(f"library GEMM 425 x 512 x 512:   {replay_us(gemm_pair) / 2:.2f} us  (the same 0.5-MB weight every launch: L2-hot)")
+# ... and with weights nobody has touched recently, as in a prompt step: a rotation of 64 matrices (32 MB: past the L2s, inside the Infinity Cache) and of
+# 640 (320 MB: past the Infinity Cache)
+for n_w, what in ((64, "32 MB of weights in rotation (L2-cold, Infinity-Cache-hot)"), (640, "320 MB in rotation (HBM-cold)")):
+    Ws = torch.randn(n_w, 512, 512, device=dev).half()
+    state = {"i": 0}
+
+    def gemm_cold():
+        i = state["i"]
+        state["i"] = (i + 2) % n_w
+        native.check(lib.grip_debug_gemm(4, p(A), p(Ws[i]), 425, 512, 512, None, None, None, p(C), None, ctypes.c_float(1.0), 512, 0, st()))
+        native.check(lib.grip_debug_gemm(4, p(C), p(Ws[i + 1]), 425, 512, 512, None, None, None, p(C2), None, ctypes.c_float(1.0), 512, 0, st()))
+    print(f"library GEMM 425 x 512 x 512:   {replay_us(gemm_cold) / 2:.2f} us  ({what})")
