@@ -75,3 +75,21 @@ for n_w, what in ((64, "32 MB of weights in rotation (L2-cold, Infinity-Cache-ho
         native.check(lib.grip_debug_gemm(4, p(A), p(Ws[i]), 425, 512, 512, None, None, None, p(C), None, ctypes.c_float(1.0), 512, 0, st()))
         native.check(lib.grip_debug_gemm(4, p(C), p(Ws[i + 1]), 425, 512, 512, None, None, None, p(C2), None, ctypes.c_float(1.0), 512, 0, st()))
     print(f"library GEMM 425 x 512 x 512:   {replay_us(gemm_cold) / 2:.2f} us  ({what})")
+
+# Producer -> consumer through a kernel boundary: does the consumer find the producer's output in ITS XCD's L2?  A ping-pong chain of elementwise kernels
+# over 425 x 512 f16 (0.4 MB) where block b of every launch reads exactly what block b of the previous launch wrote (same XCD: blocks are dealt to XCDs
+# round-robin), against chains where it reads what block b + s wrote (another XCD for s not a multiple of 8).
+n = 425 * 512
+u = torch.zeros(2 * n, device=dev, dtype=torch.float16)
+v = torch.zeros(2 * n, device=dev, dtype=torch.float16)
+
+
+def chain(shift):
+    def body():
+        torch.add(u[shift: shift + n], 1.0, out=v[:n])
+        torch.add(v[shift: shift + n], 1.0, out=u[:n])
+    return replay_us(body) / 2
+
+
+for shift in (0, 1024, 2048, 4096, 3 * 4096, 8 * 4096, 20 * 1024):
+    print(f"elementwise ping-pong 425 x 512 f16, consumer reads {shift:6d} elements further on: {chain(shift):.2f} us per dependent launch")
