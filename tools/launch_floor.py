@@ -93,3 +93,25 @@ def chain(shift):
 
 for shift in (0, 1024, 2048, 4096, 3 * 4096, 8 * 4096, 20 * 1024):
     print(f"elementwise ping-pong 425 x 512 f16, consumer reads {shift:6d} elements further on: {chain(shift):.2f} us per dependent launch")
+
+# Does a kernel cost more when the launches before it were OTHER kernels (instruction fetch: 176 different code paths per prompt step)?
+Cf = torch.empty(512, 512, dtype=torch.float32, device=dev)
+bias = torch.zeros(512, device=dev)
+
+
+def mixed():
+    native.check(lib.grip_debug_gemm(4, p(A), p(W), 425, 512, 512, None, None, None, p(C), None, ctypes.c_float(1.0), 512, 0, st()))            # f16 out
+    native.check(lib.grip_debug_layernorm(p(x), p(g_), p(b_), p(o), 425, 512, st()))
+    native.check(lib.grip_debug_gemm(0, p(C), p(W), 425, 512, 512, None, None, None, p(Cf), None, ctypes.c_float(1.0), 512, 0, st()))           # f32 out
+    native.check(lib.grip_debug_gemm(1, p(A), p(W), 425, 512, 512, p(bias), None, None, p(C2), None, ctypes.c_float(1.0), 512, 0, st()))        # + bias
+    native.check(lib.grip_debug_gemm(3, p(A), p(W), 425, 512, 512, p(bias), p(C), None, p(C2), None, ctypes.c_float(1.0), 512, 0, st()))        # + bias + residual
+
+
+def same4():
+    for _ in range(4):
+        native.check(lib.grip_debug_gemm(4, p(A), p(W), 425, 512, 512, None, None, None, p(C), None, ctypes.c_float(1.0), 512, 0, st()))
+    native.check(lib.grip_debug_layernorm(p(x), p(g_), p(b_), p(o), 425, 512, st()))
+
+
+print(f"4 GEMMs of one instantiation + 1 LayerNorm per round: {replay_us(same4):.2f} us per round of five launches")
+print(f"4 GEMMs of FOUR instantiations + 1 LayerNorm:        {replay_us(mixed):.2f} us per round of five launches")
