@@ -241,7 +241,7 @@ def gather_in_dataset_order(local_rows, n, batch_size):
     order) -> [n, ...] rows in dataset order on every rank: `accelerator.gather` + the de-duplication of the padded tail
     (textual_prompt.py:285-294; a duplicated sample's rows are identical, the first occurrence is kept)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 or n == 0:
         return local_rows[:n]
     per_rank = [[i for b in rank_batches(range(n), batch_size, r, ws) for i in b] for r in range(ws)]
     m = len(per_rank[0])
