@@ -52,8 +52,13 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     // A thread takes a PAIR of rows (2 r, 2 r + 1) and one 8-wide slice: the transposed images hold two consecutive keys of a head dim in one 32-bit
     // word (vt_index), so they are written as eight 4-byte words instead of sixteen 2-byte ones (r04: the 2-byte writes were the 39 % LDS bank
     // conflicts of profiles/r03_sq_vpt.csv), the forward's V staging pattern.
-    for (int idx = tid; idx < (SP / 2) * 8; idx += NWB * 64) {
-        const int r0 = 2 * (idx >> 3), chunk = idx & 7;
+    // r05: lanes run over ROW PAIRS (32 per 32-lane group), the 8-wide slice comes from the higher index bits -- the forward's staging map.  With eight
+    // consecutive lanes on the eight slices of ONE row pair (r04) every 4-byte write of a group landed in 4 banks (the slice only moves the address by whole
+    // 1-KiB blocks): 8-way conflicts on all 24 image writes per thread, most of the 31 % of profiles/r04_sq_vpt.csv.  Now 32 lanes hit 16 banks twice (free).
+    constexpr int ST_ITEMS = ((SP / 2 + 31) / 32) * 256;
+    for (int idx = tid; idx < ST_ITEMS; idx += NWB * 64) {
+        const int r0 = 2 * ((idx >> 8) * 32 + (idx & 31)), chunk = (idx >> 5) & 7;
+        if (r0 >= SP) continue;
         half8 k0 = {0, 0, 0, 0, 0, 0, 0, 0}, k1 = k0, v0 = k0, v1 = k0;
         if (r0 < S) {
             const half_t* rp = base + R(r0) * ld;
@@ -171,8 +176,9 @@ __global__ __launch_bounds__(NWB * 64) void attn_bwd_kernel(const half_t* __rest
     }
     __syncthreads();
     // ------------------------------------------------------------------ restage: T0 = (Q/8)^T, T1 = dO^T
-    for (int idx = tid; idx < (SP / 2) * 8; idx += NWB * 64) {
-        const int r0 = 2 * (idx >> 3), chunk = idx & 7;
+    for (int idx = tid; idx < ST_ITEMS; idx += NWB * 64) {
+        const int r0 = 2 * ((idx >> 8) * 32 + (idx & 31)), chunk = (idx >> 5) & 7;
+        if (r0 >= SP) continue;
         half8 q0 = {0, 0, 0, 0, 0, 0, 0, 0}, q1 = q0, d0 = q0, d1 = q0;
         if (r0 < S && r0 >= q_min) {      // (queries below q_min are not this sequence's: zero rows add nothing to dK / dV)
             q0 = *(const half8*)(base + R(r0) * ld + chunk * 8);
