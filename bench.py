@@ -511,6 +511,25 @@ def secondary_block(loop, lib):
     return out
 
 
+def refine_summary(rs):
+    """What one screen-and-refine pass did (pseudolabels.refine_scan's stats under stable names)."""
+    return {"rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"], "rows_reencoded_exactly": rs["rows_exact"], "tiers": rs["tiers"],
+            "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1), "nonfinite_screen_rows": rs.get("nonfinite_screen_rows", 0),
+            "calibration_rows": rs["calibration_rows"], "rounds": rs["rounds"], "scans": rs["scans"], "rows_per_round": rs["refined_per_round"],
+            "bound_form": rs["bound_form"], "bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "bound_split_f16": rs["eps_mid"],
+            "largest_deviation_seen_split_f16": rs["max_deviation_mid"], "safety": rs["safety"], "safety_split_f16": rs.get("safety_mid"),
+            "audit_rows": rs["audit_rows"], "audit_board_rows": rs["audit_board_rows"], "audit_max_deviation": rs["audit_max_deviation"],
+            "audit_widened_the_bound": rs["audit_widened"], "audits": rs["audits"], "audit_rows_split_f16": rs.get("audit_mid_rows", 0),
+            "audit_max_deviation_split_f16": rs.get("audit_max_deviation_mid", 0.0), "unverified_rows": rs["unverified_rows"],
+            "observed_rows": rs["observed_rows"]}
+
+
+REFINE_NOTE = ("bound_form 'odds': every probability's odds p / (1 - p) are trusted to a factor e^{+-bound} (the form a logit error takes; 'relative': every "
+               "probability to a relative bound); bound = safety x the largest such deviation between a tier's probabilities and the better ones that replaced "
+               "them, over every row re-encoded so far; audit = hold-out rows re-encoded after certification: audit_max_deviation <= bound or the bound is "
+               "widened and the scan repeats; unverified_rows = rows the lists take on trust within the bound")
+
+
 def structured_pool_block(loop):
     """The identical-mode pass on a pool with class structure (per-image colour cast + low-frequency ramp on top of noise, the recipe of
     grip_amd.data.synthetic generated on the device): the timed pool is i.i.d. noise, on which the random-init tower gives every image the
@@ -538,12 +557,8 @@ def structured_pool_block(loop):
         dt = time.perf_counter() - t0
         rs = loop.refine_stats
         pred_hist = np.bincount(cls, minlength=a.classes)
-        return {"pool_images": n, "identical_images_per_sec": n / dt, "rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"],
-                "rows_reencoded_exactly": rs["rows_exact"], "fraction": rs["rows_refined"] / n, "audit_rows": rs["audit_rows"],
-                "audit_max_deviation": rs["audit_max_deviation"], "audit_widened_the_bound": rs["audit_widened"],
-                "rounds": rs["rounds"], "rows_per_round": rs["refined_per_round"], "relative_bound": rs["eps"], "pairs": int(len(img)),
-                "classes_with_a_full_board": int((pred_hist >= a.k).sum()),
-                "note": "same loop, same towers, structured synthetic pool (seeded on the device; not the fixtures' CPU generator)"}
+        return dict(refine_summary(rs), pool_images=n, identical_images_per_sec=n / dt, pairs=int(len(img)), classes_with_a_full_board=int((pred_hist >= a.k).sum()),
+                    note="same loop, same towers, structured synthetic pool (seeded on the device; not the fixtures' CPU generator)")
     finally:
         loop.pool, loop.refine_stats = keep_pool, keep_stats
         loop.stage.update(keep_stage)
@@ -596,10 +611,7 @@ def stress_model_block(loop):
                 "identical_images_per_sec": n / dt, "exact_mode_images_per_sec": n / t_exact,
                 "logit_spread_max_minus_median": float(np.mean(lg.max(1) - np.median(lg, 1))), "mean_top_probability": float(p32h.max(1).mean()),
                 "distinct_argmax_classes": int(len(np.unique(a32h))),
-                "nonfinite_screen_rows": rs["nonfinite_screen_rows"], "rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"],
-                "rows_reencoded_exactly": rs["rows_exact"], "tiers": rs["tiers"], "rounds": rs["rounds"], "relative_bound": rs["eps"],
-                "largest_deviation_seen": rs["max_deviation"], "relative_bound_split_f16": rs["eps_mid"], "audit_rows": rs["audit_rows"],
-                "audit_max_deviation": rs["audit_max_deviation"], "audit_widened_the_bound": rs["audit_widened"], "unverified_rows": rs["unverified_rows"],
+                "refine": refine_summary(rs),
                 "model": "ViT-B/16 synthetic-stress (weights.stress_state_dict): four residual-stream channels at x ~ +200 on every token (LayerNorm gains compensated; fp32 vs fp64 "
                          "oracle 1e-7), last block scaled so that one stream channel of the CLS row leaves the f16 range on ~ 1/5 of the images; text features = mean-removed "
                          "prototypes of the pool's own embeddings (peaked rows: the f16 embeddings' ~1e-3 direction error becomes a logit error of ~0.3, so the measured "
@@ -855,19 +867,7 @@ def main():
         "pseudolabel_images_per_sec": images / loop.t_pl if loop.t_pl else None,
         "identical_images_per_sec": (images / loop.t_pl if loop.t_pl else None) if args.mode == "identical" else None,
         "f16_mode_loop": f16_loop,
-        "identical": None if rs is None else {
-            "rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"], "rows_reencoded_exactly": rs["rows_exact"], "tiers": rs["tiers"],
-            "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1),
-            "calibration_rows": rs["calibration_rows"], "rounds": rs["rounds"], "scans": rs["scans"], "rows_per_round": rs["refined_per_round"],
-            "relative_bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "relative_bound_split_f16": rs["eps_mid"],
-            "largest_deviation_seen_split_f16": rs["max_deviation_mid"], "safety": rs["safety"], "safety_split_f16": rs.get("safety_mid"),
-            "audit_rows": rs["audit_rows"], "audit_board_rows": rs["audit_board_rows"], "audit_max_deviation": rs["audit_max_deviation"],
-            "audit_widened_the_bound": rs["audit_widened"], "audits": rs["audits"], "audit_rows_split_f16": rs.get("audit_mid_rows", 0),
-            "audit_max_deviation_split_f16": rs.get("audit_max_deviation_mid", 0.0), "unverified_rows": rs["unverified_rows"],
-            "observed_rows": rs["observed_rows"],
-            "note": "last timed pass; bound = safety x the largest relative deviation (by the smaller value) between a tier's probabilities and the better ones that "
-                    "replaced them, over every row re-encoded so far; audit = hold-out rows re-encoded after certification: audit_max_deviation <= relative_bound "
-                    "or the bound is widened and the scan repeats; unverified_rows = rows the lists take on trust within the bound"},
+        "identical": None if rs is None else dict(refine_summary(rs), note="last timed pass; " + REFINE_NOTE),
         "train_images_per_sec": train_imgs / loop.t_tr if loop.t_tr else None,
         "algorithmic_tflops": nominal / elapsed / 1e12 / ws,
         "executed_tflops": executed / elapsed / 1e12 / ws,

@@ -38,7 +38,7 @@ typedef enum {
 const char* grip_last_error(void);
 /* ABI version of this header; the host layer refuses a library that reports another one. */
 int grip_abi_version(void);
-#define GRIP_ABI_VERSION 7
+#define GRIP_ABI_VERSION 8
 
 /* ------------------------------------------------------------------------------------------
  * Tower description.  kind 0 = vision transformer (clip_model.visual, wrapped by
@@ -275,10 +275,19 @@ int grip_leaderboard_scan(const float* probs, const int32_t* pred, const int64_t
  * rel_eps to 0 and calls again; the marked set grows strictly, so the loop ends (host side: grip_amd.pseudolabels.refine_scan).
  *   k == 10000000 (the reference's "label everything" branch, :27-44): out_img / out_class need capacity n and every row
  *   whose arg-max is undecidable is marked.  Otherwise capacity c * min(k, n) as above.
- *   ambiguous [n] uint8 host (overwritten). */
+ *   ambiguous [n] uint8 host (overwritten).
+ *   bound_form (ABI 8): 0 = the RELATIVE form above.  1 = LOG-ODDS: rel_eps[i] is delta_i and the proviso reads "the ODDS p / (1 - p) of every
+ *   entry of row i are within a factor e^{+-delta_i} of the true ones": the interval of an entry is [p / (p + (1 - p) e^delta),
+ *   p / (p + (1 - p) e^-delta)] (with 2^-20 of slack for the f32 evaluation of p and 1 - p, and abs_eps).  It is what an error of a cheaper tower's
+ *   embedding direction produces -- the LOGITS move by scale * <de, t_c> whatever the probabilities are, and the softmax
+ *   (utils/clip_pseudolabels.py:38) turns a spread d of those errors over the classes into a factor within e^{+-d} on every entry's odds.  For
+ *   p << 1 it is the relative form with eps = e^delta - 1; for the p ~ 0.9+ entries that sit on the board thresholds of a peaked pool it is
+ *   (1 - p) times tighter.  delta < 700.
+ *   threads (ABI 8): worker threads of the scan's pre-filter; 0 = $GRIP_SCAN_THREADS, else the CPUs the process may use divided by
+ *   $LOCAL_WORLD_SIZE (at most 16).  The lists and marks do not depend on it. */
 int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps, float abs_eps,
-                                  int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count,
-                                  uint8_t* ambiguous, int64_t* n_ambiguous);
+                                  int bound_form, int threads, int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class,
+                                  int64_t* out_count, uint8_t* ambiguous, int64_t* n_ambiguous);
 
 /* ------------------------------------------------------------------------------------------
  * clip.tokenize's byte-level BPE (host function; the reference tokenises on every CustomTextEncoder.forward,

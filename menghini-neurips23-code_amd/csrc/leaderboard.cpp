@@ -128,7 +128,18 @@ extern "C" int grip_leaderboard_scan(const float* probs, const int32_t* pred, co
 //      bounds.  An exact tie between two FINAL (eps = 0) values across the boundary of a board is the one case this argument does not cover
 //      (the reference's outcome then depends on arrival order); the scan then falls back to the strict form, in which every single
 //      comparison of the literal algorithm is certified (mode 1 below).
+//
+// Two forms of the per-row bound (ABI 8, `bound_form`):
+//  0  RELATIVE: |true - s| <= eps s + abs_eps, the interval [s (1 - eps) - abs_eps, s (1 + eps) + abs_eps].
+//  1  LOG-ODDS: the ODDS s / (1 - s) of every entry of the row are within a factor [e^-delta, e^delta] of the true ones, delta = eps[row]:
+//     true in [s / (s + (1 - s) e^delta), s / (s + (1 - s) e^-delta)].  This is the form an error of the cheaper tower's embedding direction
+//     produces: it moves the LOGITS by scale x <de, t_c>, whatever the probabilities are, and softmax(l)_c = 1 / (1 + sum_c' exp(l_c' - l_c)) turns a
+//     spread d of the logit errors over the classes into a factor within e^{+-d} on every entry's odds.  For s << 1 it is the relative bound
+//     e^{+-delta}; for the s ~ 0.9+ entries that sit on the board thresholds of a peaked pool it is (1 - s) times tighter, which is what keeps such
+//     pools from being re-encoded wholesale.  The f32 evaluation of the softmax (s and 1 - s as floats) is covered by a relative slack kR on s
+//     and an absolute slack kU on 1 - s.  Everything below works on the intervals only and is the same for both forms.
 namespace {
+constexpr double kR = 1.0 / (1 << 20), kU = 1.0 / (1 << 20);
 struct BEntry {
     double lo, hi;      // interval of the true score
     float score;        // nominal
@@ -136,11 +147,46 @@ struct BEntry {
     int64_t rank;
     int32_t img;
 };
-// abs_eps: absolute slack of an un-refined value on top of the relative one -- below ~1e-30 a softmax output has no relative accuracy
-// left (denormals, underflow to 0), so the interval is [s (1 - eps) - abs_eps, s (1 + eps) + abs_eps]; final rows (eps == 0) carry none
-inline BEntry make_entry(float s, float eps, int64_t rank, int32_t img, double abs_eps) {
-    const double a = eps != 0.f ? abs_eps : 0.0;
-    return BEntry{(double)s * (1.0 - (double)eps) - a, (double)s * (1.0 + (double)eps) + a, s, eps, rank, img};
+// How the values of one row bound the true ones.  abs_eps: absolute slack of an un-refined value -- below ~1e-30 a softmax output has no
+// relative accuracy left (denormals, underflow to 0); final rows (eps == 0) carry none and their interval is the value itself.
+struct RowBound {
+    float eps = 0.f;            // relative bound (form 0) or delta (form 1); 0 = final
+    int form = 0;
+    double slack = 0.0;         // abs_eps of a non-final row
+    double up = 1.0;            // hi(s) <= s * up + slack for every s >= 0 (the quick / float screens)
+    double E = 1.0, invE = 1.0; // e^delta, e^-delta (form 1)
+    RowBound() {}
+    RowBound(float eps_, int form_, double abs_eps) : eps(eps_), form(form_) {
+        if (eps == 0.f) return;
+        slack = abs_eps;
+        if (form == 0) {
+            up = 1.0 + (double)eps;
+        } else {
+            E = std::exp((double)eps);
+            invE = 1.0 / E;
+            up = E * (1.0 + 8.0 * kR);           // >= E (1 + kR)^2 / (1 - kU)
+        }
+    }
+    inline void interval(double s, double& lo, double& hi) const {
+        if (eps == 0.f) { lo = hi = s; return; }
+        if (form == 0) {
+            lo = s * (1.0 - (double)eps) - slack;
+            hi = s * (1.0 + (double)eps) + slack;
+            return;
+        }
+        const double q = 1.0 - s;
+        const double a_hi = s * (1.0 + kR), a_lo = s * (1.0 - kR);
+        const double q_lo = std::max(q - kU, 0.0), q_hi = std::max(q, 0.0) + kU;
+        hi = a_hi / (a_hi + q_lo * invE) * (1.0 + kR) + slack;
+        lo = a_lo / (a_lo + q_hi * E) * (1.0 - kR) - slack;
+    }
+    inline double hi_of(double s) const { double lo, hi; interval(s, lo, hi); return hi; }
+    inline double lo_of(double s) const { double lo, hi; interval(s, lo, hi); return lo; }
+};
+inline BEntry make_entry(const RowBound& rb, float s, int64_t rank, int32_t img) {
+    BEntry e{0.0, 0.0, s, rb.eps, rank, img};
+    rb.interval((double)s, e.lo, e.hi);
+    return e;
 }
 // outcome of `a.score < x.score` over the true values: 1 certainly true, 0 certainly false, -1 undecidable
 inline int certainly_less(const BEntry& a, const BEntry& x) {
@@ -200,7 +246,7 @@ struct Marks {
 // every rank scans ALL N_total rows: 0.10 s -> 0.03 s per scan at N = 400 000 x C = 102 on 8 CPUs (tools/scan_scale.py).
 struct Prefilter {
     static constexpr int64_t BLOCK = 8192;
-    const float* probs; const int32_t* pred; const float* rel_eps; int64_t n; int c; double abs_eps;
+    const float* probs; const int32_t* pred; const float* rel_eps; int64_t n; int c; double abs_eps; int form;
     struct Buf {
         int64_t lo = 0, hi = 0;                 // rows [lo, hi)
         // (plain arrays: a std::vector would zero-fill tens of megabytes per scan)
@@ -246,14 +292,15 @@ struct Prefilter {
             const float* p = probs + i * c;
             const int js = pred[i];
             const float eps = rel_eps[i];
-            const double up = 1.0 + (double)eps, slack = eps != 0.f ? abs_eps : 0.0;
-            const double xlo = (js >= 0 && js < c) ? (double)p[js] * (1.0 - (double)eps) - slack : 0.0;
+            const RowBound rb(eps, form, abs_eps);
+            const double slack = rb.slack;
+            const double xlo = (js >= 0 && js < c) ? rb.lo_of((double)p[js]) : 0.0;
             uint16_t* cd = b.cand.get() + (i - b.lo) * c;
             uint16_t* sp = b.spill.get() + (i - b.lo) * c;
             float* cdp = b.cand_p.get() + (i - b.lo) * c;
             float* spp = b.spill_p.get() + (i - b.lo) * c;
             b.own[(size_t)(i - b.lo)] = (js >= 0 && js < c) ? p[js] : 0.f;
-            const float uf = f_above(up), sf = slack != 0.0 ? f_above(slack) : 0.f;
+            const float uf = f_above(rb.up), sf = slack != 0.0 ? f_above(slack) : 0.f;
             const float xl = eps != 0.f ? f_below(xlo) : INFINITY;     // eps == 0: no arg-max candidates at all
             for (int j = 0; j < c; ++j) {
                 const float h = p[j] * uf + sf;
@@ -266,7 +313,7 @@ struct Prefilter {
                 if (!w) continue;
                 for (int j = j8; j < j8 + 8 && j < c; ++j) {
                     if (!fl[j] || j == js) continue;
-                    const double hi = (double)p[j] * up + slack;
+                    const double hi = rb.hi_of((double)p[j]);
                     if (eps != 0.f && hi >= xlo) { cd[nc] = (uint16_t)j; cdp[nc++] = p[j]; }
                     if (!(hi < b.t_snap[(size_t)j])) { sp[ns] = (uint16_t)j; spp[ns++] = p[j]; }
                 }
@@ -333,6 +380,7 @@ struct Prefilter {
 struct BoundedScan {
     const float* probs; const int32_t* pred; const int64_t* path_rank; const float* rel_eps;
     int64_t n; int c; int64_t kk; bool strict; double abs_eps;
+    int form = 0;                   // 0 relative, 1 log-odds (RowBound)
     int threads = 1;                // > 1: the parallel pre-filter above
     std::vector<BBoard> boards;
     std::vector<double> t_lo;       // per class: T_lo once the board is sorted, -inf before (nothing is dropped then)
@@ -417,7 +465,7 @@ struct BoundedScan {
         // the parallel pre-filter (threads > 1): block b + 1 is filtered by the workers while this thread scans block b
         std::unique_ptr<Prefilter> pf;
         if (threads > 1 && n >= 2 * Prefilter::BLOCK && c <= 65535) {
-            pf.reset(new Prefilter{probs, pred, rel_eps, n, c, abs_eps});
+            pf.reset(new Prefilter{probs, pred, rel_eps, n, c, abs_eps, form});
             pf->start(threads);
             pf->request(0, 0, t_lo);
         }
@@ -431,7 +479,7 @@ struct BoundedScan {
             const int js = pred[i];
             const float eps = rel_eps[i];
             GRIP_REQUIRE(js >= 0 && js < c, "bounded leaderboard: pred[%lld] = %d out of range", (long long)i, js);
-            GRIP_REQUIRE(eps >= 0.f && eps < 1e6f, "bounded leaderboard: rel_eps[%lld] = %g out of range", (long long)i, (double)eps);    // (eps >= 1: the lower bound is <= 0, i.e. "could be anything below")
+            GRIP_REQUIRE(eps >= 0.f && eps < (form == 0 ? 1e6f : 700.f), "bounded leaderboard: rel_eps[%lld] = %g out of range", (long long)i, (double)eps);    // (relative eps >= 1: the lower bound is <= 0, i.e. "could be anything below"; log-odds: e^delta must fit a double)
             // this row's survivors of the pre-filter: arg-max candidates, and classes whose offer was not certainly irrelevant when the block was requested
             const uint16_t* cd = nullptr; const uint16_t* sp = nullptr;
             const float* cdp = nullptr; const float* spp = nullptr;
@@ -453,16 +501,16 @@ struct BoundedScan {
             } else {
                 p_own = p[js];
             }
-            const BEntry x = make_entry(p_own, eps, path_rank[i], (int32_t)i, abs_eps);
-            const double slack = eps != 0.f ? abs_eps : 0.0;     // hi(p[j]) = p[j] * up + slack
-            const double up = 1.0 + (double)eps;
+            const RowBound rb(eps, form, abs_eps);
+            const BEntry x = make_entry(rb, p_own, path_rank[i], (int32_t)i);
+            const double slack = rb.slack;
             cand.clear();                                                   // (A)
             cand_p.clear();
             if (eps != 0.f) {
                 if (cd) { cand.assign(cd, cd + ncd); cand_p.assign(cdp, cdp + ncd); }
                 else
                     for (int j = 0; j < c; ++j)
-                        if (j != js && (double)p[j] * up + slack >= x.lo) { cand.push_back(j); cand_p.push_back(p[j]); }
+                        if (j != js && rb.hi_of((double)p[j]) >= x.lo) { cand.push_back(j); cand_p.push_back(p[j]); }
             }
             if (label_all) {
                 if (!cand.empty()) mk.mark(x);
@@ -474,11 +522,15 @@ struct BoundedScan {
                 if (sp) {
                     for (int q = 0; q < nsp; ++q) {
                         const int j = sp[q];
-                        if (!((double)spp[q] * up + slack < t_lo[(size_t)j])) visit(j, spp[q]);
+                        if (!(rb.hi_of((double)spp[q]) < t_lo[(size_t)j])) visit(j, spp[q]);
                     }
                 } else {
-                    for (int j = 0; j < c; ++j)
-                        if (j != js && !((double)p[j] * up + slack < t_lo[(size_t)j])) visit(j, p[j]);
+                    for (int j = 0; j < c; ++j) {
+                        if (j == js) continue;
+                        const double t = t_lo[(size_t)j];
+                        if (p[j] >= 0.f && (double)p[j] * rb.up + slack < t) continue;      // (quick: hi(p) <= p up + slack)
+                        if (!(rb.hi_of((double)p[j]) < t)) visit(j, p[j]);
+                    }
                 }
             };
             BBoard& own = boards[(size_t)js];
@@ -486,7 +538,7 @@ struct BoundedScan {
             if (!cand.empty()) {
                 bool all_reject = certainly_rejects(js, x);
                 for (size_t q = 0; all_reject && q < cand.size(); ++q)
-                    all_reject = certainly_rejects(cand[q], make_entry(cand_p[q], eps, x.rank, x.img, abs_eps));
+                    all_reject = certainly_rejects(cand[q], make_entry(rb, cand_p[q], x.rank, x.img));
                 mk.cat = 1;
                 if (!all_reject) mk.mark(x);
             }
@@ -517,7 +569,7 @@ struct BoundedScan {
                         spill = false;
                         for_live([&](int j, float pj) {
                             BBoard& b = boards[(size_t)j];
-                            const BEntry y = make_entry(pj, eps, x.rank, x.img, abs_eps);
+                            const BEntry y = make_entry(rb, pj, x.rank, x.img);
                             b.cond.push_back(y);
                             b.hi.push(y.hi);
                         });
@@ -541,7 +593,7 @@ struct BoundedScan {
                 for_live([&](int j, float pj) {
                     BBoard& b = boards[(size_t)j];
                     const bool was = b.sorted;
-                    offer(j, make_entry(pj, eps, x.rank, x.img, abs_eps));
+                    offer(j, make_entry(rb, pj, x.rank, x.img));
                     if (!was && b.sorted) ++n_sorted;
                 });
             }
@@ -596,16 +648,22 @@ struct BoundedScan {
 }  // namespace
 
 extern "C" int grip_leaderboard_scan_bounded(const float* probs, const int32_t* pred, const int64_t* path_rank, const float* rel_eps, float abs_eps,
-                                             int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class, int64_t* out_count,
-                                             uint8_t* ambiguous, int64_t* n_ambiguous) {
+                                             int bound_form, int threads, int64_t n, int c, int64_t k, int32_t* out_img, int32_t* out_class,
+                                             int64_t* out_count, uint8_t* ambiguous, int64_t* n_ambiguous) {
     GRIP_REQUIRE(probs && pred && path_rank && rel_eps && out_img && out_class && out_count && ambiguous && n_ambiguous, "bounded leaderboard: null pointer");
     GRIP_REQUIRE(n >= 0 && c > 0 && k > 0, "bounded leaderboard: bad sizes n=%lld c=%d k=%lld", (long long)n, c, (long long)k);
     GRIP_REQUIRE(abs_eps >= 0.f && abs_eps < 1.f, "bounded leaderboard: abs_eps = %g out of range", (double)abs_eps);
+    GRIP_REQUIRE(bound_form == 0 || bound_form == 1, "bounded leaderboard: bound_form = %d (0 relative, 1 log-odds)", bound_form);
+    GRIP_REQUIRE(threads >= 0, "bounded leaderboard: threads = %d", threads);
     try {
         BoundedScan s{probs, pred, path_rank, rel_eps, n, c, std::min<int64_t>(k, std::max<int64_t>(n, 1)), false, (double)abs_eps};
         const char* env = getenv("GRIP_SCAN_STRICT");       // developer A/B: certify every comparison of the literal algorithm
         s.strict = env && env[0] == '1';
-        {   // threads of the parallel pre-filter: $GRIP_SCAN_THREADS, else the CPUs this process may use -- affinity mask, capped by the cgroup CPU quota
+        s.form = bound_form;
+        if (threads > 0) {          // the caller's choice (a root-placed scan of a multi-rank pass uses the whole node's quota)
+            s.threads = std::min(threads, 16);
+            if ((int64_t)n * c < (int64_t)4 << 20) s.threads = 1;
+        } else {   // threads of the parallel pre-filter: $GRIP_SCAN_THREADS, else the CPUs this process may use -- affinity mask, capped by the cgroup CPU quota
             // (the MI355X boxes show 256 logical CPUs under a 16-CPU quota), divided among the ranks of the node ($LOCAL_WORLD_SIZE: every rank runs the
             // replicated scan at the same moment) -- at most 16; small problems run on one
             const char* te = getenv("GRIP_SCAN_THREADS");

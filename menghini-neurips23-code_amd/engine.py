@@ -510,10 +510,15 @@ def leaderboard_scan(probs, pred, path_rank, k):
     return out_img[: m.value].copy(), out_cls[: m.value].copy()
 
 
-def leaderboard_scan_bounded(probs, pred, path_rank, rel_eps, k, abs_eps=0.0):
+BOUND_FORMS = {"relative": 0, "odds": 1}
+
+
+def leaderboard_scan_bounded(probs, pred, path_rank, rel_eps, k, abs_eps=0.0, form="relative", threads=0):
     """grip_leaderboard_scan_bounded: (img, cls, ambiguous) with ambiguous a bool [n] array of the rows the caller has to
-    re-encode more accurately before the lists can be trusted (include/grip_amd.h).  rel_eps [n]: per-row relative bound (0 = final);
-    abs_eps: absolute slack of every row with a non-zero relative bound."""
+    re-encode more accurately before the lists can be trusted (include/grip_amd.h).  rel_eps [n]: per-row bound (0 = final) -- a relative
+    bound on every probability (form "relative") or a bound on the spread of the row's logit errors (form "odds": every entry's odds
+    p / (1 - p) are known to a factor e^{+-delta});  abs_eps: absolute slack of every non-final row;  threads: worker threads of the scan's
+    pre-filter (0 = the library's default)."""
     import numpy as np
     lib = native.lib()
     probs = np.ascontiguousarray(probs, dtype=np.float32)
@@ -527,8 +532,8 @@ def leaderboard_scan_bounded(probs, pred, path_rank, rel_eps, k, abs_eps=0.0):
     amb = np.zeros(max(n, 1), dtype=np.uint8)
     m, na = c_int64(), c_int64()
     native.check(lib.grip_leaderboard_scan_bounded(c_void_p(probs.ctypes.data), c_void_p(pred.ctypes.data), c_void_p(rank.ctypes.data),
-                                                   c_void_p(eps.ctypes.data), float(abs_eps), n, c, int(k), c_void_p(out_img.ctypes.data),
-                                                   c_void_p(out_cls.ctypes.data), byref(m), c_void_p(amb.ctypes.data), byref(na)))
+                                                   c_void_p(eps.ctypes.data), float(abs_eps), BOUND_FORMS[form], int(threads), n, c, int(k),
+                                                   c_void_p(out_img.ctypes.data), c_void_p(out_cls.ctypes.data), byref(m), c_void_p(amb.ctypes.data), byref(na)))
     return out_img[: m.value].copy(), out_cls[: m.value].copy(), amb[:n].astype(bool)
 
 

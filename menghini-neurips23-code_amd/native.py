@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char, c_float, c_int, c_int32, c_int64, c_size_t, 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRIP_LIB") or os.path.join(_HERE, "libgrip_amd.so")      # GRIP_LIB: another build of the same ABI (developer A/B)
 HOST_LIB_PATH = os.environ.get("GRIP_HOST_LIB")       # developer: a sanitizer build of the host-only sources (`make -C csrc sanitize`) whose grip_leaderboard_* / grip_bpe_* replace the library's
-ABI_VERSION = 7
+ABI_VERSION = 8
 FWD_TRAIN, FWD_SHARED_PREFIX, FWD_NO_POS_EMB = 1, 2, 4      # grip_text_forward flags
 
 
@@ -68,8 +68,8 @@ _SIGS = {
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "grip_preprocess_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "grip_leaderboard_scan": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64)]),
-    "grip_leaderboard_scan_bounded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_int64, c_void_p, c_void_p, POINTER(c_int64),
-                                              c_void_p, POINTER(c_int64)]),
+    "grip_leaderboard_scan_bounded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                              POINTER(c_int64), c_void_p, POINTER(c_int64)]),
     "grip_bpe_create": (c_int, [ctypes.c_char_p, c_size_t, POINTER(c_void_p)]),
     "grip_bpe_destroy": (c_int, [c_void_p]),
     "grip_bpe_special_ids": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),

@@ -108,15 +108,28 @@ REFINE_SAFETY_MID = 4.0     # the same for the middle tier: its bound rests on a
                             # given twice the margin instead (8 x was measured: 293 instead of 222 f32 rows per pass on the bench pool, +0.025 s) -- at 1e-5-sized deviations the extra band holds a handful of rows
 REFINE_ESCALATE_AFTER = 8   # rounds after which whatever is still un-refined moves up a tier in one go (pathological pools only, see refine_scan)
 REFINE_AUDIT_ROWS = 256     # un-refined rows re-encoded AFTER the scan certified its lists, to check the bound they were trusted to ($GRIP_REFINE_AUDIT)
+REFINE_AUDIT_ROWS_LARGE = 1024   # ... for pools of REFINE_AUDIT_LARGE_POOL rows and more (what the lists take on trust there rests on a four times larger hold-out)
+REFINE_AUDIT_LARGE_POOL = 50000
 REFINE_MAX_AUDITS = 4       # audits that may each widen the bound before everything left is simply re-encoded
 REFINE_ABS_EPS = 1e-30      # absolute slack of an un-refined probability: below this a softmax output has no relative accuracy (denormals, 0)
-_EPS_CAP = 9e5              # grip_leaderboard_scan_bounded takes bounds below 1e6 (a bound >= 1 already means "anything below")
+_EPS_CAP = 9e5              # grip_leaderboard_scan_bounded takes relative bounds below 1e6 (a bound >= 1 already means "anything below")
+_DELTA_CAP = 80.0           # ... and log-odds bounds below 700 (e^80 already turns every interval into (0, 1))
+_KR = _KU = 2.0 ** -20      # the log-odds form's slack for the f32 evaluation of p and 1 - p (csrc/leaderboard.cpp: kR, kU)
 
 
-def audit_rows_default():
-    import os
+def audit_rows_default(n=0):
     v = os.environ.get("GRIP_REFINE_AUDIT", "")
-    return int(v) if v.strip() else REFINE_AUDIT_ROWS
+    return int(v) if v.strip() else (REFINE_AUDIT_ROWS_LARGE if n >= REFINE_AUDIT_LARGE_POOL else REFINE_AUDIT_ROWS)
+
+
+def bound_form():
+    """Form of the per-row bound the screen-and-refine pass works with: "odds" (default) -- every entry's odds p / (1 - p) are known to a factor
+    e^{+-delta} (include/grip_amd.h, bound_form 1: the form a logit error takes; tight for the p ~ 0.9+ entries on the board thresholds of a peaked
+    pool) -- or "relative" (rounds 3-5: one relative bound on every probability of a tier).  $GRIP_REFINE_BOUND."""
+    v = os.environ.get("GRIP_REFINE_BOUND", "odds")
+    if v not in engine.BOUND_FORMS:
+        raise ValueError(f"GRIP_REFINE_BOUND={v!r}: expected 'odds' or 'relative'")
+    return v
 
 
 def _deviation(approx, better, abs_eps):
@@ -133,6 +146,41 @@ def _deviation(approx, better, abs_eps):
     with np.errstate(divide="ignore", invalid="ignore"):
         r = np.where(d > 0, d / m, 0.0)
     return float(np.max(r))
+
+
+def odds_interval(p, delta, abs_eps):
+    """(lo, hi) of the true probability given an approximate `p` whose row obeys the log-odds bound `delta`: the numpy restatement of RowBound::interval
+    (csrc/leaderboard.cpp, bound_form 1) that _deviation_odds inverts (tests hold the two together)."""
+    s = np.asarray(p, dtype=np.float64)
+    E = np.exp(np.float64(delta))
+    q = 1.0 - s
+    a_hi, a_lo = s * (1.0 + _KR), s * (1.0 - _KR)
+    q_lo, q_hi = np.maximum(q - _KU, 0.0), np.maximum(q, 0.0) + _KU
+    with np.errstate(divide="ignore", invalid="ignore"):
+        hi = a_hi / (a_hi + q_lo / E) * (1.0 + _KR) + abs_eps
+        lo = a_lo / (a_lo + q_hi * E) * (1.0 - _KR) - abs_eps
+    return lo, hi
+
+
+def _deviation_odds(approx, better, abs_eps):
+    """Smallest delta >= 0 for which every value of `better` lies inside the log-odds interval of the corresponding value of `approx`
+    (odds_interval): the largest deviation of the rows' odds, in the form the scan uses it.  Pairs inside the absolute slack deviate by 0; an approximate
+    0 against a better value above the slack deviates infinitely."""
+    a, b = np.asarray(approx, dtype=np.float64).ravel(), np.asarray(better, dtype=np.float64).ravel()
+    if a.size == 0:
+        return 0.0
+    q = 1.0 - a
+    a_hi, a_lo = a * (1.0 + _KR), a * (1.0 - _KR)
+    q_lo, q_hi = np.maximum(q - _KU, 0.0), np.maximum(q, 0.0) + _KU
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bu = (b - abs_eps) / (1.0 + _KR)                   # upper side: bu <= a_hi / (a_hi + q_lo / E)
+        need = bu > a_hi / (a_hi + q_lo)
+        e_up = np.where(need, np.where((a_hi > 0) & (bu < 1.0), q_lo * bu / (a_hi * (1.0 - bu)), np.inf), 1.0)
+        bl = (b + abs_eps) / (1.0 - _KR)                   # lower side: bl >= a_lo / (a_lo + q_hi E)
+        need = bl < a_lo / (a_lo + q_hi)
+        e_lo = np.where(need, np.where(bl > 0, a_lo * (1.0 - bl) / (bl * q_hi), np.inf), 1.0)
+    e = max(1.0, float(np.max(e_up)), float(np.max(e_lo)))
+    return float(np.log(e)) if np.isfinite(e) else float("inf")
 
 
 def scan_placement():
@@ -156,37 +204,40 @@ def _usable_cpus():
     return n
 
 
-def scan_bounded(probs, pred, ranks, rel, k, abs_eps):
+def scan_bounded(probs, pred, ranks, rel, k, abs_eps, form="relative"):
     """engine.leaderboard_scan_bounded for the current process group: one rank, or placement "replicated": the local scan.  Placement "root": rank 0
-    runs it on every CPU the process may use (the native default divides them by $LOCAL_WORLD_SIZE) and the other ranks receive (img, cls, ambiguous)
-    in one broadcast of k C + N / 4 words -- they spend no CPU on it and cannot disagree with rank 0 (tests/test_dist_gloo.py)."""
+    runs it on every CPU the process may use (the native default divides them by $LOCAL_WORLD_SIZE; the count travels as an argument, ABI 8) and the
+    other ranks receive (img, cls, ambiguous) in one broadcast of k C + N / 4 words -- they spend no CPU on it and cannot disagree with rank 0
+    (tests/test_dist_gloo.py).  The first word of that message is the pair count, or -1 when rank 0's scan failed: every rank then raises together
+    instead of waiting in the broadcast for the collective's watchdog."""
     rank, ws = gdist.world()
     if ws == 1 or scan_placement() != "root":
-        return engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps)
+        return engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps, form=form)
     n, c = probs.shape
     cap = n if int(k) == K_ALL else c * max(1, min(int(k), n))
     words = (n + 3) // 4
     buf = np.zeros(1 + 2 * cap + words, dtype=np.int32)
+    failure = None
     if rank == 0:
-        own = "GRIP_SCAN_THREADS" not in os.environ
-        if own:
-            os.environ["GRIP_SCAN_THREADS"] = str(min(16, _usable_cpus()))
         try:
-            img, cls, amb = engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps)
-        finally:
-            if own:
-                del os.environ["GRIP_SCAN_THREADS"]
-        buf[0] = len(img)
-        buf[1: 1 + len(img)] = img
-        buf[1 + cap: 1 + cap + len(cls)] = cls
-        buf[1 + 2 * cap:].view(np.uint8)[:n] = amb
+            threads = 0 if "GRIP_SCAN_THREADS" in os.environ else min(16, _usable_cpus())
+            img, cls, amb = engine.leaderboard_scan_bounded(probs, pred, ranks, rel, k, abs_eps, form=form, threads=threads)
+            buf[0] = len(img)
+            buf[1: 1 + len(img)] = img
+            buf[1 + cap: 1 + cap + len(cls)] = cls
+            buf[1 + 2 * cap:].view(np.uint8)[:n] = amb
+        except (engine.native.GripError, MemoryError) as e:
+            failure = e
+            buf[0] = -1
     gdist.broadcast_array_(buf)
     m = int(buf[0])
+    if m < 0:
+        raise failure if failure is not None else engine.native.GripError("bounded leaderboard scan failed on rank 0 (see its log)")
     return buf[1: 1 + m].copy(), buf[1 + cap: 1 + cap + m].copy(), buf[1 + 2 * cap:].view(np.uint8)[:n].astype(bool)
 
 
 def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safety=REFINE_SAFETY, max_rounds=64, mid_rows=None,
-                audit=None, abs_eps=REFINE_ABS_EPS):
+                audit=None, abs_eps=REFINE_ABS_EPS, bound=None):
     """Leaderboard lists of the reference's fp32 scan from probabilities of the f16 towers (utils/clip_pseudolabels.py:38-112).
 
     `probs` [N, C] f32 / `pred` [N] come from the f16 image tower (the SCREEN; modified in place); `exact_rows(idx)` returns the
@@ -207,9 +258,20 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     out to deviate by MORE than the bound it was trusted to, the bound was understated: it is widened to safety x that deviation, the scan
     repeats under it and is audited again (at most REFINE_MAX_AUDITS times, after which every row left is re-encoded).  stats reports the audit (`audit_rows`, `audit_max_deviation`, `audit_widened`), the rows the final lists
     still take on trust (`unverified_rows`) and the number of rows every bound rests on (`observed_rows`).
+
+    `bound` ("odds" / "relative", default bound_form()): what a tier's bound says.  "relative": every probability of the row is within the relative
+    eps of the truth.  "odds" (r06): every entry's odds p / (1 - p) are within a factor e^{+-delta} of the truth -- the same statement for the small
+    entries, (1 - p) times tighter for the large ones, and the one an embedding-direction error actually produces (a logit error of
+    scale x <de, t_c>, whatever the probability).  Deviations are measured in the same form, entry by entry (_deviation_odds), so calibration,
+    growth and audit work unchanged; `eps` / `max_deviation` in the stats are then deltas.
     Returns (img, cls, stats)."""
     n, c = probs.shape
-    audit = audit_rows_default() if audit is None else int(audit)
+    form = bound_form() if bound is None else bound
+    if form not in engine.BOUND_FORMS:
+        raise ValueError(f"refine_scan: bound={form!r}")
+    deviation = _deviation if form == "relative" else _deviation_odds
+    cap = _EPS_CAP if form == "relative" else _DELTA_CAP
+    audit = audit_rows_default(n) if audit is None else int(audit)
     if audit > 0:
         audit = min(n, max(16, min(audit, n // 16)))       # like the calibration sample: at most 1/16 of the pool, at least 16 rows
     level = np.zeros(n, dtype=np.int8)
@@ -225,7 +287,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         for lv in (0, 1):
             sel = (level[idx] == lv) & np.isfinite(probs[idx]).all(axis=1)       # (a non-finite row says nothing about the tier's accuracy)
             if measure and sel.any():
-                dev[lv] = max(dev[lv], _deviation(probs[idx[sel]], p32[sel], abs_eps))
+                dev[lv] = max(dev[lv], deviation(probs[idx[sel]], p32[sel], abs_eps))
         probs[idx] = p32
         pred[idx] = a32
         level[idx] = 2
@@ -237,6 +299,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         if idx.size == 0:
             return
         pm, am = mid_rows(idx)
+        n_mid += idx.size           # (rows the tier ENCODED: an overflow inside it is paid for all the same)
         bad = ~np.isfinite(pm).all(axis=1)
         if bad.any():       # an overflow inside the cheaper tower (f16 range): those rows go straight to the exact tower
             to_exact(idx[bad], measure=False)
@@ -244,14 +307,14 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
             if idx.size == 0:
                 return
         # the middle tier's value is itself only known to eps[1]: a screen value within d of it is within d (1 + eps1) + eps1 of the truth
+        # (log-odds form: the two factors multiply, the deltas add)
         fin = np.isfinite(probs[idx]).all(axis=1)      # (a non-finite screen row says nothing about the tier's accuracy: as in to_exact)
         if fin.any():
-            d = _deviation(probs[idx[fin]], pm[fin], abs_eps)
-            dev[0] = max(dev[0], d * (1.0 + eps[1]) + eps[1])
+            d = deviation(probs[idx[fin]], pm[fin], abs_eps)
+            dev[0] = max(dev[0], d * (1.0 + eps[1]) + eps[1] if form == "relative" else d + eps[1] + 4 * _KR)
         probs[idx] = pm
         pred[idx] = am
         level[idx] = 1
-        n_mid += idx.size
 
     def up(idx):
         """Move rows up one tier: level 0 -> middle tier where there is one, everything else -> exact."""
@@ -262,7 +325,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         to_exact(hi)
 
     def bound(lv):
-        return min((safety if lv == 0 else max(safety, REFINE_SAFETY_MID)) * dev[lv], _EPS_CAP)
+        return min((safety if lv == 0 else max(safety, REFINE_SAFETY_MID)) * dev[lv], cap)
 
     stats = {"rows": n, "calibration_rows": 0, "rounds": 0, "scans": 0, "audits": 0, "audit_rows": 0, "audit_board_rows": 0, "audit_max_deviation": 0.0,
              "audit_widened": False}
@@ -271,13 +334,20 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         return np.empty(0, np.int32), np.empty(0, np.int32), dict(stats, rows_refined=0, rows_mid=0, rows_exact=0, eps=0.0, eps_mid=0.0, max_deviation=0.0,
                                                                     max_deviation_mid=0.0, refined_per_round=[], safety=float(safety), unverified_rows=0,
                                                                     observed_rows=0, tiers=2 + (mid_rows is not None))
-    broken = np.flatnonzero(~np.isfinite(probs).all(axis=1))       # rows the screen overflowed on (f16 range): exact at once, outside every bound --
-    stats["nonfinite_screen_rows"] = int(broken.size)               # and BEFORE the calibration, so that none of them can enter a measured deviation
-    to_exact(broken, measure=False)
-    # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than 16 (a bound from one or two rows is no bound)
-    cal = np.unique(np.linspace(0, n - 1, min(n, max(16, min(calib, n // 16)))).astype(np.int64))
-    cal = cal[level[cal] == 0]          # (a row the screen overflowed on is final already and measures nothing)
-    if mid_rows is not None:
+    broken = np.flatnonzero(~np.isfinite(probs).all(axis=1))       # rows the screen overflowed on (f16 range): up a tier at once, outside every bound --
+    stats["nonfinite_screen_rows"] = int(broken.size)               # and BEFORE the calibration, so that none of them can enter a measured deviation.
+    if mid_rows is not None:            # The middle tier keeps an f32 residual stream: it resolves them at 2.5x the exact tower's rate (what it
+        to_mid(broken)                  # overflows on itself goes on to the exact tower inside to_mid); r05 sent them to the exact tower directly
+    else:
+        to_exact(broken, measure=False)
+    # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than 16 (a bound from one or two rows is no bound) -- spread evenly over
+    # the rows the screen is still trusted on (a row it overflowed on measures nothing; with no such rows: over the pool, as before)
+    live = np.flatnonzero(level == 0)
+    want = min(live.size, max(16, min(calib, n // 16)))
+    cal = live[np.unique(np.linspace(0, live.size - 1, want).astype(np.int64))] if want else live
+    if cal.size == 0:
+        pass                            # every row is final already (an all-non-finite screen): nothing to calibrate, nothing left to trust
+    elif mid_rows is not None:
         # With a middle tier the screen's bound is calibrated against IT (every calibration row; its own error is folded in), and the middle
         # tier's bound against the exact tower on every fourth calibration row (at least 16): its deviations are f32-rounding-sized and tightly
         # distributed (three f16 products with f32 accumulation: ~3 x 2^-23 per term), the rows the scan sends on to the exact tower and the
@@ -287,11 +357,13 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         n_mid += cal_x.size
         p32_x, a32_x = exact_rows(cal_x)
         n_exact += cal_x.size
-        dev[1] = _deviation(pm_x, p32_x, abs_eps)
+        fin = np.isfinite(pm_x).all(axis=1)            # (a middle-tier overflow measures nothing either; the row is exact now anyway)
+        if fin.any():
+            dev[1] = deviation(pm_x[fin], p32_x[fin], abs_eps)
         eps[1] = bound(1)
         fin = np.isfinite(probs[cal_x]).all(axis=1)
         if fin.any():
-            dev[0] = _deviation(probs[cal_x[fin]], p32_x[fin], abs_eps)
+            dev[0] = deviation(probs[cal_x[fin]], p32_x[fin], abs_eps)
         probs[cal_x], pred[cal_x], level[cal_x] = p32_x, a32_x, 2
         to_mid(cal[level[cal] == 0])
     else:
@@ -303,7 +375,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     g = np.random.default_rng(1000003 * n + int(min(k, 1 << 30)))      # the audit's draw: a function of the problem only (identical on every rank)
     while True:
         rel = np.where(level == 2, np.float32(0), np.where(level == 1, np.float32(eps[1]), np.float32(eps[0]))).astype(np.float32)
-        img, cls, amb = scan_bounded(probs, pred, ranks, rel, k, abs_eps)
+        img, cls, amb = scan_bounded(probs, pred, ranks, rel, k, abs_eps, form)
         stats["scans"] += 1
         todo = np.flatnonzero(amb & (level < 2))
         moved = bound(0) > eps[0] or bound(1) > eps[1]
@@ -364,7 +436,8 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         eps = [max(eps[0], bound(0)), max(eps[1], bound(1))]
     stats.update(rows_refined=int((level > 0).sum()), rows_mid=int(n_mid), rows_exact=int(n_exact), refined_per_round=per_round, eps=float(eps[0]),
                  eps_mid=float(eps[1]), max_deviation=float(dev[0]), max_deviation_mid=float(dev[1]), safety=float(safety), safety_mid=float(max(safety, REFINE_SAFETY_MID)),
-                 unverified_rows=int((level == 0).sum()), observed_rows=int((level > 0).sum()), tiers=2 + (mid_rows is not None), abs_eps=float(abs_eps))
+                 unverified_rows=int((level == 0).sum()), observed_rows=int((level > 0).sum()), tiers=2 + (mid_rows is not None), abs_eps=float(abs_eps),
+                 bound_form=form)
     return img, cls, stats
 
 

@@ -29,22 +29,28 @@ struct Pool {
     std::vector<int64_t> rank;
 };
 
-static Pool make_pool(int64_t n, int c, double spread, double sigma, unsigned seed, bool dominant) {
+// form 0: the screen is the exact matrix times (1 + d sigma), |d| <= 5 (relative bound 6 sigma); form 1: the screen is the softmax of the exact
+// LOGITS plus d sigma per class (spread over the classes <= 10 sigma: the log-odds bound 11 sigma)
+static Pool make_pool(int64_t n, int c, double spread, double sigma, unsigned seed, bool dominant, int form = 0) {
     Pool p; p.n = n; p.c = c;
-    p.exact.resize((size_t)(n * c)); p.screen.resize((size_t)(n * c)); p.eps.assign((size_t)n, (float)(6 * sigma));
+    p.exact.resize((size_t)(n * c)); p.screen.resize((size_t)(n * c)); p.eps.assign((size_t)n, (float)((form ? 11 : 6) * sigma));
     p.pred_exact.resize((size_t)n); p.pred.resize((size_t)n); p.rank.resize((size_t)n);
     std::mt19937_64 g(seed);
     std::normal_distribution<double> nd(0.0, 1.0);
-    std::vector<double> z((size_t)c);
+    std::vector<double> z((size_t)c), zs((size_t)c);
     for (int64_t i = 0; i < n; ++i) {
-        double m = -1e300, s = 0;
-        for (int j = 0; j < c; ++j) { z[(size_t)j] = nd(g) * spread + (dominant && j == 1 ? 3.0 : 0.0); m = std::max(m, z[(size_t)j]); }
+        double m = -1e300, s = 0, ms = -1e300, ss = 0;
+        for (int j = 0; j < c; ++j) {
+            z[(size_t)j] = nd(g) * spread + (dominant && j == 1 ? 3.0 : 0.0); m = std::max(m, z[(size_t)j]);
+            if (form) { double d = nd(g); d = std::max(-5.0, std::min(5.0, d)); zs[(size_t)j] = z[(size_t)j] + d * sigma; ms = std::max(ms, zs[(size_t)j]); }
+        }
         for (int j = 0; j < c; ++j) { z[(size_t)j] = exp(z[(size_t)j] - m); s += z[(size_t)j]; }
+        if (form) for (int j = 0; j < c; ++j) { zs[(size_t)j] = exp(zs[(size_t)j] - ms); ss += zs[(size_t)j]; }
         int a = 0, b = 0;
         for (int j = 0; j < c; ++j) {
             const float e = (float)(z[(size_t)j] / s);
-            double d = nd(g); d = std::max(-5.0, std::min(5.0, d));
-            const float q = (float)((double)e * (1.0 + d * sigma));
+            double d = form ? 0.0 : nd(g); d = std::max(-5.0, std::min(5.0, d));
+            const float q = form ? (float)(zs[(size_t)j] / ss) : (float)((double)e * (1.0 + d * sigma));
             p.exact[(size_t)(i * c + j)] = e; p.screen[(size_t)(i * c + j)] = q;
             if (e > p.exact[(size_t)(i * c + a)]) a = j;
             if (q > p.screen[(size_t)(i * c + b)]) b = j;
@@ -57,25 +63,23 @@ static Pool make_pool(int64_t n, int c, double spread, double sigma, unsigned se
 
 struct Result { std::vector<int32_t> img, cls; std::vector<uint8_t> amb; int64_t count = 0, n_amb = 0; int rc = 0; };
 
-static Result bounded(const Pool& p, const std::vector<float>& probs, const std::vector<int32_t>& pred, const std::vector<float>& eps, int64_t k, int threads) {
+static Result bounded(const Pool& p, const std::vector<float>& probs, const std::vector<int32_t>& pred, const std::vector<float>& eps, int64_t k, int threads, int form = 0) {
     Result r;
     const int64_t cap = k == 10000000 ? p.n : (int64_t)p.c * std::min<int64_t>(k, p.n);
     r.img.assign((size_t)cap, -1); r.cls.assign((size_t)cap, -1); r.amb.assign((size_t)p.n, 7);
-    char buf[16]; snprintf(buf, sizeof buf, "%d", threads);
-    setenv("GRIP_SCAN_THREADS", buf, 1);
-    r.rc = grip_leaderboard_scan_bounded(probs.data(), pred.data(), p.rank.data(), eps.data(), 1e-30f, p.n, p.c, k, r.img.data(), r.cls.data(), &r.count,
-                                         r.amb.data(), &r.n_amb);
+    r.rc = grip_leaderboard_scan_bounded(probs.data(), pred.data(), p.rank.data(), eps.data(), 1e-30f, form, threads, p.n, p.c, k, r.img.data(), r.cls.data(),
+                                         &r.count, r.amb.data(), &r.n_amb);
     return r;
 }
 
-static void scan_case(const char* name, int64_t n, int c, double spread, double sigma, unsigned seed, bool dominant, int64_t k) {
-    Pool p = make_pool(n, c, spread, sigma, seed, dominant);
+static void scan_case(const char* name, int64_t n, int c, double spread, double sigma, unsigned seed, bool dominant, int64_t k, int form = 0) {
+    Pool p = make_pool(n, c, spread, sigma, seed, dominant, form);
     std::vector<float> probs = p.screen, eps = p.eps;
     std::vector<int32_t> pred = p.pred;
     int rounds = 0;
     int64_t refined = 0;
     for (;; ++rounds) {
-        Result a = bounded(p, probs, pred, eps, k, 1), b = bounded(p, probs, pred, eps, k, 8);
+        Result a = bounded(p, probs, pred, eps, k, 1, form), b = bounded(p, probs, pred, eps, k, 8, form);
         CHECK(a.rc == 0 && b.rc == 0, "%s: rc %d / %d", name, a.rc, b.rc);
         CHECK(a.count == b.count && a.n_amb == b.n_amb && a.img == b.img && a.cls == b.cls && a.amb == b.amb,
               "%s round %d: the threaded pre-filter changed the scan (count %lld/%lld, marked %lld/%lld)", name, rounds,
@@ -205,6 +209,11 @@ int main() {
     scan_case("wide boards", 70000, 64, 0.3, 3e-3, 4, false, 300);
     scan_case("small (single-threaded path)", 3000, 10, 0.5, 3e-3, 5, false, 3);
     scan_case("k > n / c", 5000, 7, 0.5, 3e-3, 6, false, 2000);
+    // the log-odds form of the bound (ABI 8) on additive logit noise: near-uniform, peaked (top probabilities ~ 0.9+), label-everything
+    scan_case("log-odds, near-tied", 40000, 102, 0.05, 4e-3, 11, true, 16, 1);
+    scan_case("log-odds, peaked rows", 40000, 102, 4.0, 2e-2, 12, false, 16, 1);
+    scan_case("log-odds, label everything", 40000, 102, 2.0, 1e-2, 13, false, 10000000, 1);
+    scan_case("log-odds, small", 3000, 10, 3.0, 5e-2, 14, false, 3, 1);
     bpe_cases();
     if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }
     printf("sanitize driver: all checks passed\n");
