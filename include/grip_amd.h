@@ -148,6 +148,11 @@ int grip_vit_backward_prefix(grip_tower* t, const float* grad_emb, const float* 
 #define GRIP_FWD_TRAIN 1
 #define GRIP_FWD_SHARED_PREFIX 2
 #define GRIP_FWD_NO_POS_EMB 4 /* models/clip_encoders.py:70-74, enable_pos_emb=False: the positional embedding is not added */
+#define GRIP_FWD_STREAM_HILO 8 /* grip_vit_forward, inference on an f16 tower (ABI 8): the residual stream is carried as a COMPENSATED pair of f16 numbers
+                                  (hi + lo, ~22 mantissa bits; every add into it in f32 as before), so the 2 x layers roundings of the stream no longer
+                                  accumulate -- measured: 2.5 - 3x less direction error against the f32 tower for ~2 bytes more traffic per stream element and
+                                  residual GEMM.  GEMM operands stay f16 (the hi part).  The SCREEN of the pseudolabel pass (grip_amd.pseudolabels) runs in
+                                  this mode; train-mode forwards and every other caller keep the plain f16 stream the reference's GPU path has. */
 int grip_text_forward(grip_tower* t, const int32_t* token_ids, const int32_t* eot_index, const float* prefix,
                       int n_prefix, int prefix_classes, int n_class, int seq_len, float* out_emb,
                       void* workspace, size_t workspace_bytes, int flags, uint64_t* generation, void* stream);

@@ -44,6 +44,9 @@ int grip_debug_ln_fold(const void* W, const float* gamma, const float* beta, con
 int grip_debug_gemm_split(int epi, const float* A, const float* W, int M, int N, int K, const float* bias, const float* resid, void* out,
                           void* a_split, void* w_split, int m_pad, void* stream);
 int grip_debug_split_rows(const float* x, void* out, int64_t rows, int K, void* stream);
+/* 1 when the last split-f16 GEMM launch formed the a_hi w_lo product, 0 when it ran the two-pass kernel (every element of W an f16 number:
+ * grip_debug_gemm_split checks W itself, a tower at grip_tower_finalize), -1 before any launch. */
+int grip_debug_split_last_wlo(void);
 /* Attention of a precision-2 tower: qkv [B*S, 3*H*64] f32 -> out [B*S, H*64] in the split layout (4 bytes per element).  mfma != 0: the matrix-pipe
  * kernel (csrc/attention_split.hip, S <= 320), else the f32 vector-ALU kernel writing the split layout (any S). */
 int grip_debug_attention_split(const void* qkv, void* out, int B, int S, int H, int causal, int mfma, void* stream);

@@ -86,14 +86,21 @@ def _preprocess(n_px, device):
     return ClipPreprocess(n_px, device)
 
 
-def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0, exact=None, synthetic="standard"):
+def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: int = 0, exact=None, synthetic="standard", fp16_checkpoint=None):
     """(model, preprocess).  Weights: $CLIP_WEIGHTS (a torch-saved OpenAI state_dict) when set,
     else the seeded synthetic init of grip_amd.weights (no checkpoints exist offline).
     exact=True (or GRIP_EXACT=1): f32 towers -- weights, activations, attention and residual stream in fp32, the
     arithmetic the reference's CPU path uses (clip.load(..., device="cpu") keeps fp32) -- for index-exact comparison of
     the pseudolabel lists; inference only, ~1/10 of the f16 throughput.
-    synthetic="stress": the synthetic init with outlier channels and an image-dependent f16 overflow (weights.stress_state_dict: tests / bench only)."""
+    synthetic="stress": the synthetic init with outlier channels and an image-dependent f16 overflow (weights.stress_state_dict: tests / bench only).
+    fp16_checkpoint=True (or GRIP_SYNTHETIC_FP16=1; synthetic weights only): the matrix weights rounded to f16 numbers, as every published CLIP
+    checkpoint holds them (weights.on_f16_grid) -- the f32 twin then computes on exactly the values the f16 towers hold, as the reference's CPU
+    path does on a real checkpoint."""
     d = _cfg.get_dims(name)
+    if fp16_checkpoint is None:
+        fp16_checkpoint = os.environ.get("GRIP_SYNTHETIC_FP16", "0") == "1"
+    if fp16_checkpoint:
+        synthetic = synthetic + "+fp16"
     if exact is None:
         exact = os.environ.get("GRIP_EXACT", "0") == "1"
     exact = int(exact)          # 2 = split-f16 towers (developer / tests: the middle tier on its own)
@@ -111,7 +118,7 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
     else:
         _warn_once("weights", "clip.load: no $CLIP_WEIGHTS -- using SYNTHETIC seeded random-init weights (accuracies are meaningless)")
         PROVENANCE["weights"] = "synthetic"
-        if synthetic not in ("standard", "stress"):
+        if synthetic.split("+")[0] not in ("standard", "stress"):
             raise ValueError(f"synthetic={synthetic!r}: expected 'standard' or 'stress'")
         if synthetic != "standard":
             PROVENANCE["weights"] = "synthetic-" + synthetic
@@ -131,7 +138,9 @@ def load(name: str, device="cuda", jit: bool = False, download_root=None, seed: 
 
 def _synthetic_sd(name, d, seed, variant="standard"):
     if _SD_CACHE.get("key") != (name, seed, variant):
-        _SD_CACHE.update(key=(name, seed, variant), sd=_weights.stress_state_dict(d, seed) if variant == "stress" else _weights.init_state_dict(d, seed))
+        base, _, grid = variant.partition("+")
+        sd = _weights.stress_state_dict(d, seed) if base == "stress" else _weights.init_state_dict(d, seed)
+        _SD_CACHE.update(key=(name, seed, variant), sd=_weights.on_f16_grid(sd) if grid == "fp16" else sd)
     return _SD_CACHE["sd"]
 
 

@@ -195,6 +195,11 @@ struct GemmArgs {
     // column panel says).  Changes the summation order with the tile row, so only train-mode launches may set it (the inference
     // forwards stay bit-identical under any chunking).
     int rot_rows;
+    half_t* resid_lo;   // EPI_BIAS_RESID[_STATS], f16 kernels, optional: the COMPENSATED residual stream of the screen (r06) -- the stream value of an element is
+                        // resid + resid_lo (two f16 numbers, ~22 mantissa bits): the epilogue adds both in f32, stores hi = f16(v) to `out` and lo = f16(v - hi) back
+                        // to resid_lo (same index as `out`: the stream is updated in place).  The next GEMM still multiplies the hi part alone (one operand
+                        // rounding, which does not accumulate); what no longer accumulates is the rounding of the stream itself, 24 of them per ViT-B/16 image
+    int w_exact;        // f32 == 2 only: every element of W is an f16 number (zero lo parts: fp16 checkpoints) -- gemm_split.hip drops the a_hi w_lo product
     int ablate;         // developer builds only (-DGRIP_ABLATE, tools/mlp_ablation.sh): bit 0 = the c_fc epilogue issues no global store, bit 1 = the K = 4 d
                         // residual GEMM reads its A operand from a 31-MB window (Infinity-Cache resident); timing experiments, results are wrong by design
 };
@@ -206,15 +211,16 @@ int launch_gemm_f32(int epi, const GemmArgs& a, hipStream_t s);
 // split-f16 tier (gemm_split.hip; GemmArgs.f32 == 2): A and W in the split layout ([32 x hi | 32 x lo'] f16 per 32 consecutive k, row pitch
 // 4 K bytes), f32 bias / residual / output -- EPI_BIAS_GELU_F16 writes its output in the split layout (it feeds the next split GEMM)
 int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s);
-int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight = 0, int* overflow_flag = nullptr);   // weights carry gemm_split_weight_scale()
+int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight = 0, int* overflow_flag = nullptr,
+                      int* lo_nonzero_flag = nullptr);   // weights carry gemm_split_weight_scale(); lo_nonzero_flag: set when an element is not an f16 number
 float gemm_split_weight_scale();
 
 // Activation buffers are f16 (default) or f32 (exact mode): the row kernels take untyped pointers plus the flag.  f32 == 2 (split-f16
 // tier): inputs f32 as in exact mode; launch_layernorm_f16 writes its OUTPUT (a GEMM operand) in the split layout of gemm_split.hip.
 // row-wise kernels (rowops.hip)
 int launch_im2col(const void* images, int images_f16, void* out, int out_f32, int B, int R, int patch, int Kpad, hipStream_t s);
-int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, void* x, int f32, float* rowstat, int B, int G2, int d, hipStream_t s);
+int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,   /* x_lo (last argument, optional): the lo parts of a compensated stream */
+                           const float* gamma, const float* beta, void* x, int f32, float* rowstat, int B, int G2, int d, hipStream_t s, half_t* x_lo = nullptr);
 // rowstat [M, 2] = (mean, rstd) of every row from the [M, parts, 2] partial sums the residual GEMM epilogues emit
 int launch_ln_stats_finalize(const float* stat_part, int parts, float* rowstat, int M, int d, hipStream_t s);
 // W' = f16(gamma o W) [N, K]; colsum[n] = sum_k W'[n][k]; bias_out[n] = bias[n] + sum_k beta[k] W[n][k]

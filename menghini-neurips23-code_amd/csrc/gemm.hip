@@ -153,7 +153,9 @@ __device__ __forceinline__ int slab_off(int row, int chunk) {
 // the tile -- lane l holds rows l and 64 + l in pre[0] / pre[1] -- and each row group fetches its pair with two ds_bpermute
 // instead of a global load whose latency the first pass of the epilogue cannot hide (that exposure cost the folded QKV /
 // c_fc GEMMs 8 % against their plain-bias forms).
-template <int EPI, int ROWFRAGS, bool CHECK, int PF, bool PRE = false>
+// HILO (residual epilogues, GemmArgs::resid_lo): the stream is a COMPENSATED pair -- value = resid + resid_lo -- read as such and written back as
+// hi = f16(v) -> out, lo = f16(v - hi) -> resid_lo (r06: the screen of the pseudolabel pass; the statistics are those of v either way).
+template <int EPI, int ROWFRAGS, bool CHECK, int PF, bool PRE = false, bool HILO = false>
 __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane,
                                                    const float2* pre = nullptr, const f32x4* cb = nullptr) {
     constexpr int NP = ROWFRAGS / PF;
@@ -168,6 +170,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
     // operand prefetch (residual / GELU' argument / row statistics): all row loads of a pass are issued together, and
     // the loads of pass p+1 go out before the stores of pass p, so no load ever queues behind a store.
     half4 res[2][NI];
+    half4 resl[2][HILO ? NI : 1];
     half4 aux[2][NI];
     float2 rst[2][NI];
     // Addresses: one 32-bit element offset per lane plus a wave-uniform step per row group, against the uniform base
@@ -188,6 +191,7 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
         for (int it = 0; it < NI; ++it) {
             const uint32_t o = elem_off(p, it);
             if constexpr (RESID) res[b][it] = *(const half4*)((const half_t*)g.resid + o);
+            if constexpr (RESID && HILO) resl[b][it] = *(const half4*)(g.resid_lo + o);
             if constexpr (EPI == EPI_GELUGRAD_F16) aux[b][it] = *(const half4*)((const half_t*)g.aux + o);
             if constexpr (FOLD && !PRE) {
                 int row = row0 + p * RP + it * 4 + rr;
@@ -226,7 +230,12 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                 // the add into the residual stream happens here in f32; the row statistics of what is about to be stored travel
                 // with it (per 64-column wave tile), so the LayerNorm that follows never has to re-read the stream
                 const half4 rh = res[p & 1][it];
-                v += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                if constexpr (HILO) {       // hi + lo is exact in f32 (two 11-bit numbers, |lo| <= ulp(hi) / 2)
+                    const half4 rl = resl[p & 1][it];
+                    v += (f32x4){(float)rh[0] + (float)rl[0], (float)rh[1] + (float)rl[1], (float)rh[2] + (float)rl[2], (float)rh[3] + (float)rl[3]};
+                } else {
+                    v += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                }
                 if constexpr (EPI == EPI_BIAS_RESID_STATS) {
                     const float sm = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
                     const float sq = row16_sum(__builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3]))));
@@ -248,7 +257,10 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
                 } else if constexpr (EPI == EPI_F32_SCALE) {
                     *(f32x4*)((float*)g.out + o) = v * g.scalar;
                 } else if constexpr (RESID) {
-                    *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    const half4 hi = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *(half4*)((half_t*)g.out + o) = hi;
+                    if constexpr (HILO)
+                        *(half4*)(g.resid_lo + o) = (half4){(half_t)(v[0] - (float)hi[0]), (half_t)(v[1] - (float)hi[1]), (half_t)(v[2] - (float)hi[2]), (half_t)(v[3] - (float)hi[3])};
                 } else if constexpr (EPI == EPI_BIAS_F16 || EPI == EPI_F16) {
                     *(half4*)((half_t*)g.out + o) = (half4){(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 } else if constexpr (EPI == EPI_BIAS_GELU_F16) {
@@ -279,6 +291,15 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmArgs& g, f32x4 (&ac
 template <int EPI, int ROWFRAGS, int PF = 2, bool PRE = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& g, f32x4 (&acc)[ROWFRAGS][4], float* slab, int row0, int col0, int lane,
                                               const float2* pre = nullptr, const f32x4* cb = nullptr) {
+    if constexpr (EPI == EPI_BIAS_RESID_STATS) {       // (the statistics-carrying form only: the inference path's; the train-mode residual kernels stay as they were)
+        if (g.resid_lo) {       // (wave-uniform: a launch either carries a compensated stream or it does not)
+            if (row0 + ROWFRAGS * 16 <= g.M)
+                epilogue_rows_impl<EPI, ROWFRAGS, false, PF, PRE, true>(g, acc, slab, row0, col0, lane, pre, cb);
+            else
+                epilogue_rows_impl<EPI, ROWFRAGS, true, PF, PRE, true>(g, acc, slab, row0, col0, lane, pre, cb);
+            return;
+        }
+    }
     if (row0 + ROWFRAGS * 16 <= g.M)
         epilogue_rows_impl<EPI, ROWFRAGS, false, PF, PRE>(g, acc, slab, row0, col0, lane, pre, cb);
     else
@@ -301,7 +322,7 @@ __device__ __forceinline__ float row8_sum(float v) {
     return v;
 }
 
-template <int EPI, bool CHECK, bool PRE>
+template <int EPI, bool CHECK, bool PRE, bool HILO = false>
 __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&acc)[8][4], float* slab, int row0, int col0, int lane, const float2* pre) {
     constexpr bool FOLD = (EPI == EPI_LNFOLD_F16 || EPI == EPI_LNFOLD_GELU_F16);
     constexpr bool RESID = (EPI == EPI_BIAS_RESID_STATS);
@@ -321,9 +342,13 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
         }
     };
     half8 res[2][2];
+    half8 resl[2][HILO ? 2 : 1];
     auto prefetch = [&](int p, int b) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) res[b][it] = *(const half8*)((const half_t*)g.resid + elem_off(p, it));
+        for (int it = 0; it < 2; ++it) {
+            res[b][it] = *(const half8*)((const half_t*)g.resid + elem_off(p, it));
+            if constexpr (HILO) resl[b][it] = *(const half8*)(g.resid_lo + elem_off(p, it));
+        }
     };
     f32x4 csum[2], bfold[2];
     if constexpr (FOLD) {
@@ -355,8 +380,14 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
             const uint32_t o = elem_off(p, it);
             if constexpr (RESID) {
                 const half8 rh = res[p & 1][it];
-                v[0] += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
-                v[1] += (f32x4){(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
+                if constexpr (HILO) {
+                    const half8 rl = resl[p & 1][it];
+                    v[0] += (f32x4){(float)rh[0] + (float)rl[0], (float)rh[1] + (float)rl[1], (float)rh[2] + (float)rl[2], (float)rh[3] + (float)rl[3]};
+                    v[1] += (f32x4){(float)rh[4] + (float)rl[4], (float)rh[5] + (float)rl[5], (float)rh[6] + (float)rl[6], (float)rh[7] + (float)rl[7]};
+                } else {
+                    v[0] += (f32x4){(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                    v[1] += (f32x4){(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
+                }
                 const float sm = row8_sum(((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3])));
                 // (two 4-column chains added, then the tree: the same association as the 8-byte form's 16-lane reduction, so the statistics
                 // -- and with them every later value of the row -- do not depend on which kernel family serves a launch)
@@ -391,8 +422,12 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
                         for (int h = 0; h < 2; ++h) v[h] = quick_gelu4(v[h]);
                     }
                 }
-                *(half8*)((half_t*)g.out + o) = (half8){(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
-                                                       (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
+                const half8 hi = (half8){(half_t)v[0][0], (half_t)v[0][1], (half_t)v[0][2], (half_t)v[0][3],
+                                         (half_t)v[1][0], (half_t)v[1][1], (half_t)v[1][2], (half_t)v[1][3]};
+                *(half8*)((half_t*)g.out + o) = hi;
+                if constexpr (HILO)
+                    *(half8*)(g.resid_lo + o) = (half8){(half_t)(v[0][0] - (float)hi[0]), (half_t)(v[0][1] - (float)hi[1]), (half_t)(v[0][2] - (float)hi[2]), (half_t)(v[0][3] - (float)hi[3]),
+                                                        (half_t)(v[1][0] - (float)hi[4]), (half_t)(v[1][1] - (float)hi[5]), (half_t)(v[1][2] - (float)hi[6]), (half_t)(v[1][3] - (float)hi[7])};
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -401,6 +436,15 @@ __device__ __forceinline__ void epilogue_rows8_impl(const GemmArgs& g, f32x4 (&a
 
 template <int EPI, bool PRE>
 __device__ __forceinline__ void epilogue_rows8(const GemmArgs& g, f32x4 (&acc)[8][4], float* slab, int row0, int col0, int lane, const float2* pre) {
+    if constexpr (EPI == EPI_BIAS_RESID_STATS) {
+        if (g.resid_lo) {
+            if (row0 + 128 <= g.M)
+                epilogue_rows8_impl<EPI, false, PRE, true>(g, acc, slab, row0, col0, lane, pre);
+            else
+                epilogue_rows8_impl<EPI, true, PRE, true>(g, acc, slab, row0, col0, lane, pre);
+            return;
+        }
+    }
     if (row0 + 128 <= g.M)
         epilogue_rows8_impl<EPI, false, PRE>(g, acc, slab, row0, col0, lane, pre);
     else

@@ -262,7 +262,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g, int tile
 #define SP1_BN 256
 #define SP1_STAGE_B ((SP1_BM + SP1_BN) * SPL_ROWB)     // 64 KiB
 #define SP1_W_SCALE 256.0f
-template <int EPI>
+// WLO = false (r06, GemmArgs::w_exact): every element of W is an f16 number already (its lo part is zero) -- what the block weights of every
+// published CLIP checkpoint are (fp16 archives; the reference's CPU path is clip.load(..., "cpu") = those values cast up, models/clip_encoders.py:
+// 108-119) -- so the a_hi w_lo product is dropped: two MFMA passes instead of three per fragment pair, the W lo fragments are never read.
+// grip_tower_finalize sets the flag when the split of the weights left no non-zero lo part.
+template <int EPI, bool WLO>
 __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nwg = tiles_m * tiles_n;
@@ -326,26 +330,27 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
 #pragma unroll
         for (int j = 1; j < 4; ++j) wh[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_hi);
         __builtin_amdgcn_sched_barrier(0);
-        // stage kt + 1 into the other slot, one piece after every twelfth MFMA (past the end: a valid slice into a slot nobody reads)
+        // stage kt + 1 into the other slot, one piece after every twelfth (WLO: eighth) MFMA (past the end: a valid slice into a slot nobody reads)
         char* abase = lds + ((kt + 1) & 1) * SP1_STAGE_B + wave * 32 * SPL_ROWB;
         char* bbase = lds + ((kt + 1) & 1) * SP1_STAGE_B + SP1_BM * SPL_ROWB + wave * 32 * SPL_ROWB;
         const char* as = a_src + (size_t)ks_stage * SPL_ROWB;
         const char* ws = w_src + (size_t)ks_stage * SPL_ROWB;
         ks_stage = next_slice(ks_stage);
+        constexpr int NQ = WLO ? 96 : 64, PIECE_EVERY = NQ / 8, LO_READS = WLO ? 12 : 8;
 #pragma unroll
-        for (int q = 0; q < 96; ++q) {        // three passes over the 32 fragment pairs (j-major): w_hi a_hi, w_lo a_hi, w_hi a_lo
+        for (int q = 0; q < NQ; ++q) {        // passes over the 32 fragment pairs (j-major): w_hi a_hi, [w_lo a_hi,] w_hi a_lo
             const int pass = q >> 5, j = (q >> 3) & 3, i = q & 7;
             if (pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
-            else if (pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
+            else if (WLO && pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
-            if (q < 24 && !(q & 1)) {         // a lo read after every other MFMA of the first 24: w_lo 0..3, then a_lo 0..7
-                const int r = q >> 1;
+            if (q < 2 * LO_READS && !(q & 1)) {         // a lo read after every other MFMA of the first pass: [w_lo 0..3, then] a_lo 0..7
+                const int r = (q >> 1) + (WLO ? 0 : 4);
                 if (r < 4) wl[r] = *(const half8*)(st + b_row + r * 16 * SPL_ROWB + swz_lo);
                 else al[r - 4] = *(const half8*)(st + a_row + (r - 4) * 16 * SPL_ROWB + swz_lo);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (q % 12 == 11) {
-                const int pc = q / 12;
+            if (q % PIECE_EVERY == PIECE_EVERY - 1) {
+                const int pc = q / PIECE_EVERY;
                 if (pc < 4) __builtin_amdgcn_global_load_lds((const AS1 void*)(as + (size_t)pc * 8 * pitch + lane_off), (AS3 void*)(abase + pc * 8 * SPL_ROWB), 16, 0, 0);
                 else __builtin_amdgcn_global_load_lds((const AS1 void*)(ws + (size_t)(pc - 4) * 8 * pitch + lane_off), (AS3 void*)(bbase + (pc - 4) * 8 * SPL_ROWB), 16, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
 // `overflow` (weights only, may be null): set to 1 when a scaled element leaves the finite f16 range -- its hi part would be inf and every row
 // of the tower non-finite (that used to end as a silent escalation of the whole pool to the f32 tower).
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, half_t* __restrict__ out, int64_t rows, int K, int64_t ld_in, float scale,
-                                                         int* __restrict__ overflow) {
+                                                         int* __restrict__ overflow, int* __restrict__ lo_nonzero) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int k4 = K >> 2;
     if (i >= rows * k4) return;
@@ -394,6 +399,10 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     if (overflow) {
         const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (!(m < 65520.0f)) *overflow = 1;            // 65520 rounds to inf in f16; NaN lands here too (benign race: every writer stores 1)
+    }
+    if (lo_nonzero) {       // weights: does any element need its lo part?  (none does when the checkpoint holds f16 numbers: GemmArgs::w_exact)
+        const bool exact = (float)(half_t)v.x == v.x && (float)(half_t)v.y == v.y && (float)(half_t)v.z == v.z && (float)(half_t)v.w == v.w;
+        if (!exact) *lo_nonzero = 1;
     }
     store4(SplitRow{out + r * 2 * (int64_t)K}, c >> 2, v);
 }
@@ -406,14 +415,17 @@ float gemm_split_weight_scale() {
 #endif
 }
 
-int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight, int* overflow_flag) {
+int launch_split_rows(const float* x, void* out, int64_t rows, int K, int64_t ld_in, hipStream_t s, int is_weight, int* overflow_flag, int* lo_nonzero_flag) {
     GRIP_REQUIRE(K % 32 == 0 && rows > 0 && ld_in >= K && ld_in % 4 == 0, "split_rows: need K %% 32 == 0 (rows=%lld K=%d ld=%lld)", (long long)rows, K, (long long)ld_in);
     const int64_t n = rows * (K / 4);
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (half_t*)out, rows, K, ld_in, is_weight ? gemm_split_weight_scale() : 1.0f,
-                       overflow_flag);
+                       overflow_flag, lo_nonzero_flag);
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;
 }
+
+static int g_last_wlo = -1;
+int gemm_split_last_wlo() { return g_last_wlo; }     // test hook: did the last launch form the a_hi w_lo product (1) or skip it (0)?
 
 int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s) {
     GRIP_REQUIRE(a.K % 64 == 0 && a.M > 0, "gemm_split: need K %% 64 == 0 (M=%d N=%d K=%d)", a.M, a.N, a.K);
@@ -422,25 +434,32 @@ int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s) {
 #if GRIP_SPLIT_LO_SCALE == 1
     constexpr int BM = SP1_BM, BN = SP1_BN;
     constexpr size_t lds = (size_t)2 * SP1_STAGE_B;
-#define GRIP_SPLIT_KERNEL gemm_split1_kernel
+#define GRIP_SPLIT_KERNEL(E, WLO) gemm_split1_kernel<E, WLO>
 #else
     constexpr int BM = SPL_BM, BN = SPL_BN;
     constexpr size_t lds = (size_t)SPL_NST * SPL_STAGE_B;
-#define GRIP_SPLIT_KERNEL gemm_split_kernel
+#define GRIP_SPLIT_KERNEL(E, WLO) gemm_split_kernel<E>
 #endif
     GRIP_REQUIRE(a.N % BN == 0, "gemm_split: need N %% %d == 0 (N=%d)", BN, a.N);
+    static const bool force_wlo = getenv("GRIP_SPLIT_WLO") && atoi(getenv("GRIP_SPLIT_WLO")) == 1;      // developer A/B: always form the a_hi w_lo product
+    const bool wlo = !a.w_exact || force_wlo;
+    g_last_wlo = wlo;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = a.N / BN;
     GRIP_REQUIRE(a.m_pad >= (int64_t)tiles_m * BM, "gemm_split: A must be allocated up to the 256-row tile (M=%d m_pad=%lld)", a.M, (long long)a.m_pad);
     dim3 grid(tiles_m * tiles_n), block(512);
-#define GRIP_GEMM_CASE(E)                                                                                                   \
-    case E: {                                                                                                               \
+#define GRIP_GEMM_LAUNCH(E, WLO)                                                                                            \
+    {                                                                                                                       \
         static bool configured = false;                                                                                     \
         if (!configured) {                                                                                                  \
-            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)GRIP_SPLIT_KERNEL<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)GRIP_SPLIT_KERNEL(E, WLO), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             configured = true;                                                                                              \
         }                                                                                                                   \
-        hipLaunchKernelGGL((GRIP_SPLIT_KERNEL<E>), grid, block, lds, s, a, tiles_m, tiles_n);                               \
-    } break;
+        hipLaunchKernelGGL((GRIP_SPLIT_KERNEL(E, WLO)), grid, block, lds, s, a, tiles_m, tiles_n);                          \
+    }
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E:                                                                                                                 \
+        if (wlo) GRIP_GEMM_LAUNCH(E, true) else GRIP_GEMM_LAUNCH(E, false)                                                  \
+        break;
     switch (epi) {
         GRIP_GEMM_CASE(EPI_F32)
         GRIP_GEMM_CASE(EPI_BIAS_F16)
@@ -449,6 +468,7 @@ int launch_gemm_split(int epi, const GemmArgs& a, hipStream_t s) {
         default: GRIP_REQUIRE(false, "gemm_split: epilogue %d is not part of the split-f16 (inference) path", epi);
     }
 #undef GRIP_GEMM_CASE
+#undef GRIP_GEMM_LAUNCH
 #undef GRIP_SPLIT_KERNEL
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;

@@ -91,7 +91,7 @@ template <int NV, typename RT>
 __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ prefix, int P,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              RT* __restrict__ x, float* __restrict__ rowstat, int B, int G2, int d) {
+                                                              RT* __restrict__ x, float* __restrict__ rowstat, int B, int G2, int d, half_t* __restrict__ x_lo) {
     const int lane = threadIdx.x & 63;
     const int S = 1 + P + G2;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -119,6 +119,12 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
             const f32x4 g = ((const f32x4*)gamma)[lane + 64 * i], bb = ((const f32x4*)beta)[lane + 64 * i];
             v[i] = ln_apply(v[i], mean, rstd, g, bb);
             store4(o, lane + 64 * i, v[i]);
+            if constexpr (sizeof(RT) == 2) {
+                if (x_lo) {     // compensated stream: what the f16 rounding of the value just stored dropped
+                    const f32x4 r = {v[i][0] - (float)(half_t)v[i][0], v[i][1] - (float)(half_t)v[i][1], v[i][2] - (float)(half_t)v[i][2], v[i][3] - (float)(half_t)v[i][3]};
+                    store4(x_lo + (size_t)row * d, lane + 64 * i, r);
+                }
+            }
         }
     if (rowstat) {     // statistics of the row just written, for the LayerNorm folded into the first QKV GEMM
         ln_normalize<NV>(v, lane, d4, d, mean, rstd);
@@ -127,12 +133,12 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const float* __res
 }
 
 int launch_vit_assemble_ln(const float* patch_out, const float* cls, const float* pos, const float* prefix, int P,
-                           const float* gamma, const float* beta, void* x, int f32, float* rowstat, int B, int G2, int d, hipStream_t s) {
+                           const float* gamma, const float* beta, void* x, int f32, float* rowstat, int B, int G2, int d, hipStream_t s, half_t* x_lo) {
     const int rows = B * (1 + P + G2);
     if (f32) {
-        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, float>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (float*)x, rowstat, B, G2, d));
+        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, float>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (float*)x, rowstat, B, G2, d, (half_t*)nullptr));
     } else {
-        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, resid_t>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (resid_t*)x, rowstat, B, G2, d));
+        DISPATCH_NV(d, hipLaunchKernelGGL((vit_assemble_ln_kernel<NV, resid_t>), dim3((rows + 3) / 4), dim3(256), 0, s, patch_out, cls, pos, prefix, P, gamma, beta, (resid_t*)x, rowstat, B, G2, d, x_lo));
     }
     GRIP_CHECK_HIP(hipGetLastError());
     return GRIP_OK;

@@ -196,6 +196,8 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     half_t* row_datt = nullptr;   // [Bp, d]
     float* stat_part = nullptr;// [d/64, M, 2] partial row sums emitted by the residual GEMM epilogues (f16 towers)
     float* rowstat = nullptr;  // [Mp, 2] (mean, rstd) of the residual stream's rows, consumed by the LayerNorm-folded GEMMs
+    half_t* x_lo = nullptr;    // inference, f16 towers: the lo parts of the stream when the forward runs with GRIP_FWD_STREAM_HILO (GemmArgs::resid_lo)
+    int hilo = 0;              // ... and whether this forward does
     // train-mode saves, one per layer (x_in has layers+1 entries)
     std::vector<resid_t*> x_in, x_mid;
     std::vector<half_t*> qkv_l, att_l, hpre_l;
@@ -228,6 +230,7 @@ struct grip_tower {
     half_t* w16;      // GEMM-operand blob: f16, or f32 when f32 != 0 (exact mode) -- always addressed through wop()
     float* w32;
     int f32 = 0;      // dims.precision != 0: activations, residual stream, attention and the operand blob's primary slots are f32 (inference only)
+    int w_exact = 0;  // precision 2: no block weight has a non-zero lo part (set by grip_tower_finalize; GemmArgs::w_exact)
     int split = 0;    // dims.precision == 2: the four GEMMs of a block run on the split-f16 kernel (gemm_split.hip); their A operands are written in
                       // its layout by the producers (LayerNorm, f32 attention, GELU epilogue), their weights by grip_tower_finalize (#S slots)
     uint64_t generation = 0;   // counts train-mode forwards (see `pending`)
@@ -282,6 +285,7 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     size_t off = 0;
     auto take = [&](size_t nbytes) { char* p = base ? base + off : nullptr; off += (nbytes + 255) / 256 * 256; return (void*)p; };
     if (!train) w.x = (resid_t*)take(w.Mp * d * es);
+    if (!train && !t->f32) w.x_lo = (half_t*)take(w.Mp * d * 2);      // lo parts of a compensated stream (GRIP_FWD_STREAM_HILO)
     w.xn = (half_t*)take(w.Mp * d * es);
     if (!train) { w.qkv = (half_t*)take(w.Mp * 3 * d * es); w.att = (half_t*)take(w.Mp * d * es); }
     w.h = (half_t*)take(w.Mp * 4 * d * es);
@@ -395,19 +399,21 @@ extern "C" int grip_tower_finalize(grip_tower* t, void* stream) {
             if ((rc = launch_ln_fold_weights(t->w16 + w.fc_w, F + w.ln2_g, F + w.ln2_b, F + w.fc_b, t->w16 + w.fc_wG, F + w.fc_cs, F + w.fc_bb, 4 * d, d, s))) return rc;
         }
     if (t->split) { // split-layout copies of the block weights (the f32 originals stay: patch embedding and the final projection use them)
-        int* flag = nullptr;        // raised by the split kernel when a scaled weight leaves the f16 range (finalize is a one-off: a sync here is fine)
-        GRIP_CHECK_HIP(hipMalloc((void**)&flag, sizeof(int)));
-        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+        int* flag = nullptr;        // [0] raised by the split kernel when a scaled weight leaves the f16 range, [1] when a weight is not an f16 number
+        GRIP_CHECK_HIP(hipMalloc((void**)&flag, 2 * sizeof(int)));      // (finalize is a one-off: a sync here is fine)
+        hipError_t e = hipMemsetAsync(flag, 0, 2 * sizeof(int), s);
         rc = e == hipSuccess ? GRIP_OK : GRIP_ERR_HIP;
         for (const LayerW& w : t->L.layer) {
             if (rc) break;
-            if ((rc = launch_split_rows((const float*)t->wop(w.in_w), t->wop(w.in_wS), 3 * d, d, d, s, 1, flag))) break;
-            if ((rc = launch_split_rows((const float*)t->wop(w.out_w), t->wop(w.out_wS), d, d, d, s, 1, flag))) break;
-            if ((rc = launch_split_rows((const float*)t->wop(w.fc_w), t->wop(w.fc_wS), 4 * d, d, d, s, 1, flag))) break;
-            if ((rc = launch_split_rows((const float*)t->wop(w.proj_w), t->wop(w.proj_wS), d, 4 * d, 4 * d, s, 1, flag))) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.in_w), t->wop(w.in_wS), 3 * d, d, d, s, 1, flag, flag + 1))) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.out_w), t->wop(w.out_wS), d, d, d, s, 1, flag, flag + 1))) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.fc_w), t->wop(w.fc_wS), 4 * d, d, d, s, 1, flag, flag + 1))) break;
+            if ((rc = launch_split_rows((const float*)t->wop(w.proj_w), t->wop(w.proj_wS), d, 4 * d, 4 * d, s, 1, flag, flag + 1))) break;
         }
-        int over = 0;
-        if (!rc && (hipMemcpyAsync(&over, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = GRIP_ERR_HIP;
+        int flags[2] = {0, 0};
+        if (!rc && (hipMemcpyAsync(flags, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = GRIP_ERR_HIP;
+        const int over = flags[0];
+        t->w_exact = flags[1] == 0;         // fp16 checkpoints: no block weight needs its lo part (GemmArgs::w_exact)
         (void)hipFree(flag);
         if (rc == GRIP_ERR_HIP) { grip_set_error("tower_finalize: HIP error while splitting the weights"); return rc; }
         if (rc) return rc;
@@ -469,6 +475,9 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
     // 2.2 of the block's 2.9 GFLOP per ViT-B/16 image are never issued, the embedding is unchanged.  GRIP_LAST_BLOCK_FULL=1
     // computes the whole block as the reference does (A/B; the tests hold the two paths equal).
     const bool rows_only = fold && !w.train && !last_block_full() && !w.Ps;
+    // Compensated stream (GRIP_FWD_STREAM_HILO; inference, folded f16 towers): the two residual epilogues of a block read hi + lo and write both; everything
+    // else (the GEMMs' A operand, the last block's gathered rows, ln_post) reads the hi part, i.e. the stream as an f16 tower has always seen it.
+    const bool hilo = w.hilo && fold && !w.train && w.x_lo;
     *compact = false;
     for (int l = 0; l < t->D.layers; ++l) {
         const LayerW& lw = t->L.layer[(size_t)l];
@@ -509,24 +518,24 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             float* qkv32 = (float*)(void*)w.qkv;
             GemmArgs a{};
             RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, gf, w.M, d, s));
-            a.f32 = gf; a.A = w.xn; a.W = in_w + wb; a.M = w.M; a.m_pad = w.Mp; a.N = 2 * d; a.K = d; a.bias = F + lw.in_b + d; a.out = qkv32 + d; a.ldc = 3 * d;
+            a.f32 = gf; a.w_exact = t->w_exact; a.A = w.xn; a.W = in_w + wb; a.M = w.M; a.m_pad = w.Mp; a.N = 2 * d; a.K = d; a.bias = F + lw.in_b + d; a.out = qkv32 + d; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_BIAS_F16, a, s));
             RUN(launch_gather_rows4(x, read_rows, w.S, w.row_x, w.batch, d, s));
             RUN(launch_gather_rows4(w.xn, read_rows, w.S, w.row_xn, w.batch, d, s));
             a = GemmArgs{};
-            a.f32 = gf; a.A = w.row_xn; a.W = in_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.in_b; a.out = w.row_h; a.ldc = d;
+            a.f32 = gf; a.w_exact = t->w_exact; a.A = w.row_xn; a.W = in_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.in_b; a.out = w.row_h; a.ldc = d;
             RUN(launch_gemm(EPI_BIAS_F16, a, s));
             RUN(launch_attention_row_f32(qkv32, (const float*)(const void*)w.row_h, read_rows, (float*)(void*)w.row_att, w.batch, w.S, H, causal, s, t->split));
             a = GemmArgs{};
-            a.f32 = gf; a.A = w.row_att; a.W = t->wop(t->split ? lw.out_wS : lw.out_w); a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.out_b;
+            a.f32 = gf; a.w_exact = t->w_exact; a.A = w.row_att; a.W = t->wop(t->split ? lw.out_wS : lw.out_w); a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.out_b;
             a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
             RUN(launch_gemm(EPI_BIAS_RESID, a, s));
             RUN(launch_layernorm_f16(w.row_x, F + lw.ln2_g, F + lw.ln2_b, w.row_xn, gf, w.batch, d, s));
             a = GemmArgs{};
-            a.f32 = gf; a.A = w.row_xn; a.W = t->wop(t->split ? lw.fc_wS : lw.fc_w); a.M = w.batch; a.m_pad = Bp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.row_h; a.ldc = 4 * d;
+            a.f32 = gf; a.w_exact = t->w_exact; a.A = w.row_xn; a.W = t->wop(t->split ? lw.fc_wS : lw.fc_w); a.M = w.batch; a.m_pad = Bp; a.N = 4 * d; a.K = d; a.bias = F + lw.fc_b; a.out = w.row_h; a.ldc = 4 * d;
             RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
             a = GemmArgs{};
-            a.f32 = gf; a.A = w.row_h; a.W = t->wop(t->split ? lw.proj_wS : lw.proj_w); a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b;
+            a.f32 = gf; a.w_exact = t->w_exact; a.A = w.row_h; a.W = t->wop(t->split ? lw.proj_wS : lw.proj_w); a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b;
             a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
             RUN(launch_gemm(EPI_BIAS_RESID, a, s));
             x = w.row_x;
@@ -568,7 +577,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         a.rot_rows = w.train;     // train-mode GEMMs may stagger their K walks by tile row (common.h)
         if (!fold) {
             RUN(launch_layernorm_f16(x, F + lw.ln1_g, F + lw.ln1_b, w.xn, gf, w.M, d, s));
-            a.f32 = gf; a.A = w.xn; a.W = t->wop(t->split ? lw.in_wS : lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
+            a.f32 = gf; a.w_exact = t->w_exact; a.A = w.xn; a.W = t->wop(t->split ? lw.in_wS : lw.in_w); a.M = w.M; a.m_pad = w.Mp; a.N = 3 * d; a.K = d; a.bias = F + lw.in_b; a.out = qkv; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_BIAS_F16, a, s));
             if (t->split && attention_split_supported(w.S)) RUN(launch_attention_fwd_split((const float*)(const void*)qkv, att, w.batch, w.S, H, causal, s));
             else if (f) RUN(launch_attention_fwd_f32((const float*)(const void*)qkv, (float*)(void*)att, w.batch, w.S, H, causal, s, t->split));
@@ -582,14 +591,15 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         }
         a = GemmArgs{};
         a.rot_rows = w.train;
-        a.f32 = gf; a.A = att; a.W = t->wop(t->split ? lw.out_wS : lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
+        a.f32 = gf; a.w_exact = t->w_exact; a.A = att; a.W = t->wop(t->split ? lw.out_wS : lw.out_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = x; a.out = x_mid; a.ldc = d;
         a.stat_part = fold ? w.stat_part : nullptr;
+        a.resid_lo = hilo ? w.x_lo : nullptr;
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         a = GemmArgs{};
         a.rot_rows = w.train;
         if (!fold) {
             RUN(launch_layernorm_f16(x_mid, F + lw.ln2_g, F + lw.ln2_b, w.xn, gf, w.M, d, s));
-            a.f32 = gf; a.A = w.xn; a.W = t->wop(t->split ? lw.fc_wS : lw.fc_w); a.bias = F + lw.fc_b;
+            a.f32 = gf; a.w_exact = t->w_exact; a.A = w.xn; a.W = t->wop(t->split ? lw.fc_wS : lw.fc_w); a.bias = F + lw.fc_b;
         } else {
             if (parts_in) { a.stat_in = w.stat_part; a.stat_parts = parts; }
             else RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
@@ -600,8 +610,9 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
         RUN(launch_gemm(fold ? EPI_LNFOLD_GELU_F16 : EPI_BIAS_GELU_F16, a, s));
         a = GemmArgs{};
         a.rot_rows = w.train;
-        a.f32 = gf; a.A = w.h; a.W = t->wop(t->split ? lw.proj_wS : lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
-        a.stat_part = (!fold || last) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
+        a.f32 = gf; a.w_exact = t->w_exact; a.A = w.h; a.W = t->wop(t->split ? lw.proj_wS : lw.proj_w); a.M = w.M; a.m_pad = w.Mp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = x_mid; a.out = x_out; a.ldc = d;
+        a.stat_part = (!fold || (last && !hilo)) ? nullptr : w.stat_part;     // the final LayerNorm (CLS / EOT rows only) reads the stream itself
+        a.resid_lo = hilo ? w.x_lo : nullptr;      // (the compensated form lives in the statistics-carrying epilogue: the last block's unread sums are its price)
         if (w.train && w.coop_ks > 1) { a.ksplit = w.coop_ks; a.coop_scratch = w.coop_scratch; a.coop_counter = w.coop_cnt; }
         RUN(launch_gemm(EPI_BIAS_RESID, a, s));
         if (fold && !last && !parts_in) RUN(launch_ln_stats_finalize(w.stat_part, parts, w.rowstat, w.M, d, s));
@@ -642,8 +653,9 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
                                 int batch, float* out_emb, void* workspace, size_t workspace_bytes, int flags, uint64_t* generation, void* stream) {
     try {
         GRIP_REQUIRE(t && t->D.kind == 0, "vit_forward: not a vision tower");
-        GRIP_REQUIRE((flags & ~(GRIP_FWD_TRAIN | GRIP_FWD_NO_POS_EMB)) == 0, "vit_forward: unknown flag bits 0x%x", flags);
+        GRIP_REQUIRE((flags & ~(GRIP_FWD_TRAIN | GRIP_FWD_NO_POS_EMB | GRIP_FWD_STREAM_HILO)) == 0, "vit_forward: unknown flag bits 0x%x", flags);
         const int train = flags & GRIP_FWD_TRAIN;
+        GRIP_REQUIRE(!(flags & GRIP_FWD_STREAM_HILO) || (!train && !t->f32), "vit_forward: GRIP_FWD_STREAM_HILO is an inference mode of the f16 towers");
         GRIP_REQUIRE(images && out_emb && (n_prefix == 0 || prefix), "vit_forward: null pointer");
         Workspace w;
         RUN(check_ws(t, batch, n_prefix, train, workspace, workspace_bytes, w));
@@ -656,7 +668,9 @@ extern "C" int grip_vit_forward(grip_tower* t, const void* images, int images_f1
         a.f32 = f; a.A = w.patches; a.W = t->wop(t->L.conv_w); a.M = batch * G2; a.m_pad = round_up64((int64_t)batch * G2, 256); a.N = d; a.K = t->L.kpad; a.out = w.patch_out; a.ldc = d;
         RUN(launch_gemm(EPI_F32, a, s));
         resid_t* x0 = train ? w.x_in[0] : w.x;
-        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, (train && !train_fold(t)) ? nullptr : w.rowstat, batch, G2, d, s));
+        w.hilo = (flags & GRIP_FWD_STREAM_HILO) ? 1 : 0;
+        RUN(launch_vit_assemble_ln(w.patch_out, F + t->L.cls, (flags & GRIP_FWD_NO_POS_EMB) ? nullptr : F + t->L.pos, prefix, n_prefix, F + t->L.lnpre_g, F + t->L.lnpre_b, x0, f, (train && !train_fold(t)) ? nullptr : w.rowstat, batch, G2, d, s,
+                                   w.hilo ? w.x_lo : nullptr));
         resid_t* xf = nullptr;
         bool compact = false;
         RUN(run_blocks(t, w, x0, /*causal=*/0, nullptr, s, &xf, &compact));
@@ -761,11 +775,20 @@ extern "C" int grip_debug_gemm_split(int epi, const float* A, const float* W, in
                                      void* a_split, void* w_split, int m_pad, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     RUN(launch_split_rows(A, a_split, m_pad, K, K, s));
-    RUN(launch_split_rows(W, w_split, N, K, K, s, 1));
+    int* flag = nullptr;        // as grip_tower_finalize: is every element of W an f16 number?  (then the two-product kernel runs: GemmArgs::w_exact)
+    GRIP_CHECK_HIP(hipMalloc((void**)&flag, sizeof(int)));
+    int inexact = 1;
+    int rc = hipMemsetAsync(flag, 0, sizeof(int), s) == hipSuccess ? launch_split_rows(W, w_split, N, K, K, s, 1, nullptr, flag) : GRIP_ERR_HIP;
+    if (!rc && (hipMemcpyAsync(&inexact, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) rc = GRIP_ERR_HIP;
+    (void)hipFree(flag);
+    if (rc) return rc;
     GemmArgs a{};
+    a.w_exact = !inexact;
     a.f32 = 2; a.A = a_split; a.W = w_split; a.M = M; a.N = N; a.K = K; a.m_pad = m_pad; a.bias = bias; a.resid = resid; a.out = out; a.ldc = N;
     return launch_gemm(epi, a, s);
 }
+int gemm_split_last_wlo();
+extern "C" int grip_debug_split_last_wlo(void) { return gemm_split_last_wlo(); }
 // f32 rows -> the split layout (out: 4 bytes per element), e.g. to read a split-layout result back on the host side of a test
 extern "C" int grip_debug_split_rows(const float* x, void* out, int64_t rows, int K, void* stream) {
     return launch_split_rows(x, out, rows, K, K, (hipStream_t)stream);

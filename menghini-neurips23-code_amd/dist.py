@@ -74,6 +74,15 @@ def _via_host():
     return dist.get_backend() == "gloo"
 
 
+def trace(line):
+    """$GRIP_COMM_TRACE=<file>: one line per collective this process enters ("rank<r> <op> tag=<what> ..."), whatever the transport (torch's RCCL
+    group, gloo, the C ABI's communicator).  Developer / test switch: tests/test_gpu_dist.py counts the exchange steps of a pass with it."""
+    path = os.environ.get("GRIP_COMM_TRACE")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"rank{world()[0]} {line}\n")
+
+
 class NativeComm:
     """The C ABI's own RCCL communicator (include/grip_amd.h: grip_comm_*, grip_allgather_embeddings, grip_allreduce_mean):
     what a host that is not PyTorch binds for the two exchange steps.  The ncclUniqueId travels through torch.distributed's
@@ -103,10 +112,7 @@ class NativeComm:
             self.handle = None
 
     def _trace(self, what):
-        path = os.environ.get("GRIP_COMM_TRACE")      # developer / test switch: one line per native collective
-        if path:
-            with open(path, "a") as f:
-                f.write(what + "\n")
+        trace("native " + what)
 
     def allgather(self, local, per):
         from . import native
@@ -152,13 +158,14 @@ def shard_range(n, rank=None, world_size=None):
     return lo, hi, per
 
 
-def allgather_rows(local, n_total, per):
+def allgather_rows(local, n_total, per, tag="rows"):
     """local [<= per, E] rows of this rank's shard -> [n_total, E] in global order on every rank.
-    Pads the last shard to `per` rows and drops the padding after the gather."""
+    Pads the last shard to `per` rows and drops the padding after the gather.  `tag` names the exchange step in $GRIP_COMM_TRACE."""
     rank, ws = world()
     if ws == 1 and native_comm() is None:
         return local[:n_total]
     e = local.shape[1]
+    trace(f"allgather tag={tag} rows_per_rank={per} width={e} ranks={ws}")
     if local.shape[0] != per:
         pad = torch.zeros(per, e, dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
@@ -175,7 +182,7 @@ def allgather_rows(local, n_total, per):
     return out[:n_total]
 
 
-def allgather_selected(local_rows, idx, n_total):
+def allgather_selected(local_rows, idx, n_total, tag="selected_rows"):
     """Rows of a scattered selection of the pool on every rank.  `idx`: ascending global row numbers, the same array on every
     rank (the rows a screen-and-refine scan asked for); `local_rows` [m_r, E]: this rank's rows of `idx` that fall into its
     contiguous shard (shard_range), in order.  Returns [len(idx), E] in the order of `idx`.  One all-gather, padded to the
@@ -190,7 +197,7 @@ def allgather_selected(local_rows, idx, n_total):
     counts = np.diff(bounds)
     assert local_rows.shape[0] == counts[rank], (local_rows.shape, counts, rank)
     m = int(max(counts.max(), 1))
-    out = allgather_rows(local_rows, ws * m, m)
+    out = allgather_rows(local_rows, ws * m, m, tag=tag)
     pick = np.concatenate([r * m + np.arange(counts[r], dtype=np.int64) for r in range(ws)])
     return out[torch.as_tensor(pick, device=out.device)]
 
@@ -246,7 +253,7 @@ def gather_in_dataset_order(local_rows, n, batch_size):
     per_rank = [[i for b in rank_batches(range(n), batch_size, r, ws) for i in b] for r in range(ws)]
     m = len(per_rank[0])
     assert all(len(p) == m for p in per_rank) and local_rows.shape[0] == m, (local_rows.shape, [len(p) for p in per_rank])
-    flat = allgather_rows(local_rows.reshape(m, -1), ws * m, m)
+    flat = allgather_rows(local_rows.reshape(m, -1), ws * m, m, tag="per_sample_rows")
     import numpy as np
     uniq, first = np.unique(np.array([i for p in per_rank for i in p], dtype=np.int64), return_index=True)      # position of each sample's FIRST occurrence
     assert len(uniq) == n and uniq[0] == 0 and uniq[-1] == n - 1
@@ -258,6 +265,7 @@ def broadcast_array_(a, src=0):
     rank, ws = world()
     if ws == 1:
         return a
+    trace(f"broadcast bytes={a.nbytes} src={src}")
     t = torch.from_numpy(a)
     if _via_host():
         dist.broadcast(t, src=src)
@@ -287,6 +295,7 @@ def allreduce_mean_(tensors):
     if (ws == 1 and native_comm() is None) or not tensors:
         return
     flat = torch.cat([t.reshape(-1) for t in tensors])
+    trace(f"allreduce_mean n={flat.numel()} ranks={ws}")
     if _via_host() and flat.is_cuda:
         h = flat.cpu()
         dist.all_reduce(h)

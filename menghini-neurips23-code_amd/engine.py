@@ -191,12 +191,14 @@ class Tower:
         return out, ws
 
     @torch.no_grad()
-    def encode_chunks(self, images, out, lo, hi, chunk, prefix=None, streams=2):
+    def encode_chunks(self, images, out, lo, hi, chunk, prefix=None, streams=2, hilo=False):
         """Inference encode of images[lo:hi] into out[0:hi-lo] in chunks, alternating between two HIP streams (each
         with its own workspace): the HBM-bound kernels of one chunk (LayerNorm, attention, patch gather) run next to
         the power-bound GEMMs of the other.  Rows are independent of the chunking, so the result is bit-identical to
         a single-stream pass (+6 % on the 50k-image pass).  streams=1 keeps everything on the current stream (per-kernel
-        timings are only meaningful that way).  `images` is a tensor or a callable (a, b) -> tensor."""
+        timings are only meaningful that way).  `images` is a tensor or a callable (a, b) -> tensor.
+        hilo=True (f16 towers): the residual stream as a compensated f16 pair (GRIP_FWD_STREAM_HILO, include/grip_amd.h): the screen
+        of the pseudolabel pass -- a different (more accurate) function of the image than the plain f16 stream's, equally chunk-independent."""
         if not self._finalized:
             self.finalize()
         P = 0 if prefix is None else prefix.shape[-2]
@@ -227,7 +229,8 @@ class Tower:
                     x.record_stream(self._enc_streams[k])
                 o = out[s - lo: e - lo]
                 p, n = self._aligned(self._enc_ws[k])
-                native.check(self.lib.grip_vit_forward(self.handle, _ptr(x), int(x.dtype == torch.float16), _ptr(prefix), P, e - s, _ptr(o), p, n, 0, None,
+                native.check(self.lib.grip_vit_forward(self.handle, _ptr(x), int(x.dtype == torch.float16), _ptr(prefix), P, e - s, _ptr(o), p, n,
+                                                       native.FWD_STREAM_HILO if (hilo and self.precision == 0) else 0, None,
                                                        c_void_p((self._enc_streams[k] if streams == 2 else main).cuda_stream)))
         for st in self._enc_streams:
             main.wait_stream(st)
@@ -554,7 +557,9 @@ def masked_stream(device, quarters=3):
     import ctypes
     import os
     dev = torch.device(device)
-    key = (dev.index or 0, quarters)
+    if dev.index is None:           # "cuda": the CURRENT device, not device 0
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, quarters)
     if key in _MASKED_STREAMS:
         return _MASKED_STREAMS[key]
     out = None

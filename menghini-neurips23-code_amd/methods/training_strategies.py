@@ -214,8 +214,11 @@ class TrainingStrategy:
         (dist.rank_batches = accelerate's BatchSamplerShard; `accelerator.prepare(loader)`, e.g. textual_prompt.py:239) -- so N ranks take one
         optimizer step on N x BATCH_SIZE samples with the gradients averaged (DDP behind accelerator.backward, :131).  The shuffle seed is the same
         on every rank (`LOADER_SEED`, default 0: unpinnable upstream)."""
-        sampler = gdist.RankBatchSampler(len(data), int(self.config.BATCH_SIZE), shuffle, seed=int(getattr(self.config, "LOADER_SEED", 0)))
-        return torch.utils.data.DataLoader(data, batch_sampler=sampler)
+        seed = int(getattr(self.config, "LOADER_SEED", 0))
+        sampler = gdist.RankBatchSampler(len(data), int(self.config.BATCH_SIZE), shuffle, seed=seed)
+        # (the loader gets its own generator: without one every iter(loader) draws a base seed from the GLOBAL torch RNG, which would shift the stream
+        # the prompt re-initialisations of the GRIP iterations read -- ADVICE r5)
+        return torch.utils.data.DataLoader(data, batch_sampler=sampler, generator=torch.Generator().manual_seed(seed + 1))
 
     def _class_space(self, only_seen):
         classes = self.seen_classes if only_seen else self.classes

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRIP_LIB") or os.path.join(_HERE, "libgrip_amd.so")      # GRIP_LIB: another build of the same ABI (developer A/B)
 HOST_LIB_PATH = os.environ.get("GRIP_HOST_LIB")       # developer: a sanitizer build of the host-only sources (`make -C csrc sanitize`) whose grip_leaderboard_* / grip_bpe_* replace the library's
 ABI_VERSION = 8
-FWD_TRAIN, FWD_SHARED_PREFIX, FWD_NO_POS_EMB = 1, 2, 4      # grip_text_forward flags
+FWD_TRAIN, FWD_SHARED_PREFIX, FWD_NO_POS_EMB, FWD_STREAM_HILO = 1, 2, 4, 8      # grip_vit_forward / grip_text_forward flags
 
 
 class GripError(RuntimeError):
@@ -101,6 +101,7 @@ _DEBUG_SIGS = {          # kernel-level test hooks (csrc/tower.hip), not part of
     "grip_debug_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "grip_debug_gemm_split": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "grip_debug_split_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "grip_debug_split_last_wlo": (c_int, []),
     "grip_debug_attention_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

@@ -80,17 +80,29 @@ def path_ranks(paths):
     return r
 
 
+def screen_stream():
+    """Residual stream of the f16 tower when it SCREENS a pool for identical_lists: "hilo" (default) -- a compensated pair of f16 numbers per element
+    (GRIP_FWD_STREAM_HILO: the 24 roundings of the stream of a ViT-B/16 image no longer accumulate; the embeddings' direction error against the f32
+    tower drops 2.5 - 3x, and the measured bound of the screen with it) -- or "f16" (rounds 1-5: the plain stream).  Only the screen: train-mode
+    forwards, evaluation and the f16 MODE keep the f16 stream the reference's GPU path has.  $GRIP_SCREEN_STREAM."""
+    v = os.environ.get("GRIP_SCREEN_STREAM", "hilo")
+    if v not in ("hilo", "f16"):
+        raise ValueError(f"GRIP_SCREEN_STREAM={v!r}: expected 'hilo' or 'f16'")
+    return v
+
+
 @torch.no_grad()
-def encode_pool(visual_tower, images, chunk=880, prefix=None, out=None):
+def encode_pool(visual_tower, images, chunk=880, prefix=None, out=None, screen=False):
     """Encode an ordered pool.  `images` is a tensor [N,3,R,R] (any device) or a callable
     (lo, hi) -> tensor for that slice.  With torch.distributed initialised the pool is sharded
-    contiguously and the embeddings are all-gathered; returns [N, E] f32 on the device."""
+    contiguously and the embeddings are all-gathered; returns [N, E] f32 on the device.
+    screen=True: this is the screen of a screen-and-refine pass (screen_stream() picks the tower's stream form)."""
     n = images.shape[0] if torch.is_tensor(images) else images.n
     lo, hi, per = gdist.shard_range(n)
     dev = visual_tower.device
     local = torch.empty(max(hi - lo, 0), visual_tower.embed_dim, dtype=torch.float32, device=dev)
-    visual_tower.encode_chunks(images, local, lo, hi, chunk, prefix)
-    return gdist.allgather_rows(local, n, per)
+    visual_tower.encode_chunks(images, local, lo, hi, chunk, prefix, hilo=screen and screen_stream() == "hilo")
+    return gdist.allgather_rows(local, n, per, tag="pool_embeddings")
 
 
 def leaderboard(probs, pred, paths, class_labels, k):
@@ -284,6 +296,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         if idx.size == 0:
             return
         p32, a32 = exact_rows(idx)
+        stats["tier_calls"] += 1
         for lv in (0, 1):
             sel = (level[idx] == lv) & np.isfinite(probs[idx]).all(axis=1)       # (a non-finite row says nothing about the tier's accuracy)
             if measure and sel.any():
@@ -299,6 +312,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         if idx.size == 0:
             return
         pm, am = mid_rows(idx)
+        stats["tier_calls"] += 1
         n_mid += idx.size           # (rows the tier ENCODED: an overflow inside it is paid for all the same)
         bad = ~np.isfinite(pm).all(axis=1)
         if bad.any():       # an overflow inside the cheaper tower (f16 range): those rows go straight to the exact tower
@@ -327,7 +341,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     def bound(lv):
         return min((safety if lv == 0 else max(safety, REFINE_SAFETY_MID)) * dev[lv], cap)
 
-    stats = {"rows": n, "calibration_rows": 0, "rounds": 0, "scans": 0, "audits": 0, "audit_rows": 0, "audit_board_rows": 0, "audit_max_deviation": 0.0,
+    stats = {"rows": n, "calibration_rows": 0, "rounds": 0, "scans": 0, "tier_calls": 0, "audits": 0, "audit_rows": 0, "audit_board_rows": 0, "audit_max_deviation": 0.0,
              "audit_widened": False}
     eps = [0.0, 0.0]
     if n == 0:
@@ -356,6 +370,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         pm_x, _ = mid_rows(cal_x)
         n_mid += cal_x.size
         p32_x, a32_x = exact_rows(cal_x)
+        stats["tier_calls"] += 2
         n_exact += cal_x.size
         fin = np.isfinite(pm_x).all(axis=1)            # (a middle-tier overflow measures nothing either; the row is exact now anyway)
         if fin.any():
@@ -506,7 +521,7 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
         _, _, LAST_REFINE_STATS = refine_scan(np.empty((0, max(len(class_labels), 1)), np.float32), np.empty(0, np.int32), np.empty(0, np.int64), k, None)
         LAST_REFINE_STATS["rows_refined_this_rank"] = 0
         return [], []
-    emb = emb16 if emb16 is not None else encode_pool(visual16, images, chunk=chunk, prefix=prefix)
+    emb = emb16 if emb16 is not None else encode_pool(visual16, images, chunk=chunk, prefix=prefix, screen=True)
     dev = emb.device
     _, probs, am_l, am_p = engine.cosine_head(emb, txt_exact, scale)
     probs_h = probs.cpu().numpy()
@@ -521,7 +536,7 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
             if len(mine):
                 tower.encode_chunks(lambda a, b: take_images(images, mine[a:b]), local, 0, len(mine), tier_chunk, prefix, streams=tier_streams())
             encoded[tier] += len(mine)
-            got = gdist.allgather_selected(local, idx, n)
+            got = gdist.allgather_selected(local, idx, n, tag="refined_rows")
             _, p, al, ap = engine.cosine_head(got, txt_exact, scale)
             return p.cpu().numpy(), (ap if argmax_on == "probs" else al).cpu().numpy()
         return rows

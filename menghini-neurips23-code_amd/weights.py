@@ -105,6 +105,20 @@ def init_state_dict(d: ClipDims, seed: int = 0, logit_scale: float = math.log(10
     return out
 
 
+def on_f16_grid(sd):
+    """The state dict with every matrix operand rounded to the nearest f16 number (kept as float32): what a PUBLISHED CLIP checkpoint holds.  OpenAI's
+    archives store the convolution / Linear / attention / projection weights in fp16 (clip.model.convert_weights), and the reference's CPU path --
+    clip.load(name, "cpu"), methods/clip_baseline.py:39-41 -- computes in fp32 on those values cast up: its weights ARE f16 numbers.  The seeded
+    synthetic init is not; with this applied the f16 towers round no weight (as with a real checkpoint) and the split-f16 tier drops its a_hi w_lo
+    product (csrc/gemm_split.hip, GemmArgs::w_exact).  Embeddings tables and vectors (biases, LayerNorm affine) stay as they are: the towers keep
+    them in f32 either way."""
+    out = {}
+    for k, v in sd.items():
+        matrix = v.ndim >= 2 and not k.endswith("positional_embedding") and "token_embedding" not in k
+        out[k] = v.astype(np.float16).astype(np.float32) if matrix else v
+    return out
+
+
 STRESS_OUTLIER_CHANNELS = (5, 77, 300, 511)     # (taken modulo the vision width)
 STRESS_OVERFLOW_GAIN = (100.0, 800.0)           # (last block ln_2 gain, one c_proj output row): that CLS stream channel is ~ N(0, (5e4)^2) at ViT-B/16, a fifth of the images beyond 65 504
 

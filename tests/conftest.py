@@ -40,3 +40,36 @@ def oracle_clip():
     """The CPU oracle's `clip` stand-in (tests only)."""
     import importlib
     return importlib.import_module("oracle.clip")
+
+
+_ORACLE_LOGITS = {}
+
+
+def oracle_logits(name, images, template, classnames):
+    """logits_per_image of the reference loop on the CPU oracle -- clip_model(image[None], text) image by image, as utils/clip_pseudolabels.py:31-37
+    runs it -- for a pool of images.  They do not depend on k, and several GPU tests ask for the same pool: computed once per (model, prompts, pool
+    content) and process (the live oracle was 200 of the GPU suite's 620 seconds in r05)."""
+    import hashlib
+    import torch
+    from oracle import wrappers as W
+    key = (name, template, tuple(classnames), tuple(images.shape), hashlib.sha256(images.contiguous().numpy().tobytes()).hexdigest())
+    if key not in _ORACLE_LOGITS:
+        oc = oracle_clip()
+        om, _ = oc.load(name)
+        text = oc.tokenize(W.zero_shot_prompt_strings(template, classnames))
+        with torch.no_grad():
+            _ORACLE_LOGITS[key] = torch.cat([om(images[i:i + 1], text)[0] for i in range(images.shape[0])])
+    return _ORACLE_LOGITS[key]
+
+
+def write_report(name, payload):
+    """Per-case evidence of a GPU test as a JSON file: tests/_out/<name> (what the round-end driver pulls from the GPU box) and, where the box has a
+    gpurun_out/ to merge back, gpurun_out/tests_out/<name>.  Assertions stay in the tests; this keeps the numbers behind them."""
+    import json
+    for d in (os.path.join(REPO, "tests", "_out"), os.path.join(REPO, "gpurun_out", "tests_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                json.dump(payload, f, indent=1, default=str)
+        except OSError:
+            pass

@@ -126,6 +126,9 @@ def test_trained_prompt_probabilities_match_the_reference(tmp_path, monkeypatch,
     assert 1 - cos(txt16.float().cpu(), torch.from_numpy(fx[f"{modality}.txt_feats"]), dim=1).min().item() <= 1e-4
 
 
+SUB_ULP_MARGIN = 2.0 ** -17      # one ulp of an fp32 logit in [64, 128) (100 x cosine), as a relative step of the probability it produces
+
+
 class _Sub:
     """One case of an assign_unselected_*.npz file under the key names of the selected fixtures."""
 
@@ -154,7 +157,7 @@ def test_unselected_seeds(tmp_path, monkeypatch, group, modality):
     seeds = sorted({int(k.split(".")[1]) for k in fx.files if k.startswith(modality + ".") and k.endswith(".meta")})
     assert len(seeds) == (10 if group == "small" else 4)
     identical = same_set = 0
-    report = []
+    report, rows = [], []
     for seed in seeds:
         sub = _Sub(fx, modality, seed)
         m, data, meta = _strategy(sub, modality, monkeypatch, tmp_path, False)
@@ -168,10 +171,19 @@ def test_unselected_seeds(tmp_path, monkeypatch, group, modality):
         identical += got == want
         same_set += set(got) == set(want)
         report.append(f"{seed}: margin {margin:.1e} {'identical' if got == want else 'same set' if set(got) == set(want) else f'overlap {overlap:.3f}'}")
-        if margin >= PROB_TOL[group]:
-            assert got == want, f"{group}.{modality} seed {seed}: margin {margin:.2e} is above the fp32 deviation, yet the lists differ"
+        rows.append({"seed": seed, "margin": margin, "identical": got == want, "same_pair_set": set(got) == set(want), "overlap": overlap, "pairs": len(want)})
+        if margin >= SUB_ULP_MARGIN:
+            assert got == want, f"{group}.{modality} seed {seed}: margin {margin:.2e} is above one fp32 ulp of the logits, yet the lists differ"
         else:
             assert overlap >= 0.9, (seed, overlap)
         del m
         torch.cuda.empty_cache()
     print(f"{group}.{modality}: {identical} of {len(seeds)} un-selected seeds list-identical, {same_set} with the same pair set; " + "; ".join(report))
+    from conftest import write_report
+    write_report(f"unselected_seeds_{group}_{modality}.json", {"group": group, "modality": modality, "seeds": len(seeds), "list_identical": identical,
+                                                              "same_pair_set": same_set, "sub_ulp_margin": SUB_ULP_MARGIN, "cases": rows})
+    # The allowance, numbered: a seed may differ from the reference's list ONLY when the reference's own decision margin is below one fp32 ulp of
+    # the logits it compared (SUB_ULP_MARGIN: its outcome then hangs on the last bit of its BLAS), and at most ONE such seed per (group, modality).
+    # Measured r05 / r06: 42 of 42 identical -- the allowance has never been used.
+    sub_ulp = sum(r["margin"] < SUB_ULP_MARGIN for r in rows)
+    assert identical >= len(seeds) - min(1, sub_ulp), (identical, len(seeds), rows)

@@ -158,7 +158,13 @@ def test_trainer_is_data_parallel_like_accelerate(tmp_path, graph):
 
 
 def test_bench_two_ranks(tmp_path):
-    env = _env(tmp_path)
+    """`bench.py --gpus 2` as the driver launches it (two ranks sharing this box's GPU over gloo): the JSON line, and -- so that the first run on a
+    real multi-GPU node can only fail on RCCL, not on plumbing -- the exchange steps of the timed pass read from $GRIP_COMM_TRACE:
+    exactly ONE all-gather of the pool embeddings, one all-gather per re-encode call of a refinement tier, one broadcast per bounded scan
+    (root-placed), one all-gather of the selected training images, one gradient all-reduce per prompt step; and stage (iv) walks the shards
+    dist.rank_batches deals (the 102-step / 13-step arithmetic of DESIGN 6 at this size)."""
+    from grip_amd import dist as gdist
+    env = dict(_env(tmp_path), GRIP_COMM_TRACE=str(tmp_path / "comm.log"))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                           "--pool", "1320", "--chunk", "220"], env=env, capture_output=True, text=True, timeout=1200, cwd=tmp_path)
@@ -174,7 +180,19 @@ def test_bench_two_ranks(tmp_path):
     st = d["stage_seconds_over_ranks"]
     assert set(st) == {"encode_f16", "allgather", "head_scan", "refine_split", "refine_exact", "train"} and all(v["max_s"] >= v["min_s"] >= 0 for v in st.values())
     assert d["identical"]["tiers"] == 3 and d["identical"]["rows_reencoded_split_f16"] >= d["identical"]["rows_reencoded_exactly"]
-    assert [r["rank"] for r in d["ranks_seen"]] == [0, 1]
+    assert [r["rank"] for r in d["ranks_seen"]] == [0, 1] and len(d["ranks_seen"]) == 2
+    m_pairs, n_steps = d["config"]["selected_pairs"], d["config"]["prompt_steps_per_pass"]
+    assert n_steps == len(gdist.rank_batches(range(m_pairs), 16, 0, 2)) == len(gdist.rank_batches(range(m_pairs), 16, 1, 2)) == -(-(-(-m_pairs // 16)) // 2)
+    for r in (0, 1):
+        mine = [l.split(" ", 1)[1] for l in open(tmp_path / "comm.log").read().splitlines() if l.startswith(f"rank{r} ")]
+        timed = mine[mine.index("marker timed_begin") + 1: mine.index("marker timed_end")]
+        count = lambda key: sum(key in l for l in timed)      # noqa: E731
+        assert count("allgather tag=pool_embeddings") == 1, timed
+        assert count("allgather tag=refined_rows") == d["identical"]["tier_calls"] > 0, (timed, d["identical"])
+        assert count("broadcast ") == d["identical"]["scans"] > 0, timed
+        assert count("allgather tag=train_images") == 1, timed
+        assert count("allreduce_mean ") == n_steps, (count("allreduce_mean "), n_steps)
+        assert len(timed) == 2 + d["identical"]["tier_calls"] + d["identical"]["scans"] + n_steps, timed      # ... and nothing else
 
 
 def test_bench_strong_scaling_mode_and_native_comm_single_rank(tmp_path):

@@ -1,0 +1,101 @@
+"""The compensated residual stream of the SCREEN (r06, GRIP_FWD_STREAM_HILO; csrc/gemm.hip epilogue_rows* HILO, csrc/tower.hip run_blocks): the f16
+vision tower carries its stream as hi + lo (two f16 numbers per element), so the 2 x layers roundings of the stream no longer accumulate.  What must
+hold: (a) the embeddings move 2x or more closer to the f32 twin's than the plain f16 stream's (measured 2.5 - 3x at ViT-B/16, tools/delta_probe.py:
+the f16 stream's roundings are most of the f16 tower's deviation); (b) a row does not depend on the chunk it is encoded in -- across kernel families
+(the persistent 256 x 256 GEMMs of a pool-sized launch and the small-M kernels of a 40-image one must agree bit for bit), with and without a visual
+prompt; (c) the plain stream is untouched (no flag: the embeddings of rounds 1-5).  The reference decides on fp32 values
+(utils/clip_pseudolabels.py:38-41); the screen only has to be close to them and honest about how close (pseudolabels.refine_scan measures it)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc(tower, x, chunk, prefix=None, hilo=False):
+    out = torch.empty(x.shape[0], tower.embed_dim, device=x.device)
+    with torch.no_grad():
+        tower.encode_chunks(x, out, 0, x.shape[0], chunk, prefix, streams=1, hilo=hilo)
+    torch.cuda.synchronize()
+    return out
+
+
+def _dir_err(e, ref):
+    u = lambda t: t / t.norm(dim=-1, keepdim=True)      # noqa: E731
+    return (u(e) - u(ref)).norm(dim=-1)
+
+
+@pytest.mark.parametrize("name,n,res,big,small", [("ViT-B/16", 288, 224, 288, 40), ("small", 96, 64, 96, 7)])
+def test_compensated_stream_is_closer_to_the_f32_twin_and_chunk_independent(name, n, res, big, small):
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, rng
+    from grip_amd.data.synthetic import structured_images
+    m, _ = clip.load(name, device="cuda")
+    twin = m.exact_twin()
+    x = torch.cat([structured_images(77, lo, min(lo + 96, n), res) for lo in range(0, n, 96)]).cuda()
+    prefix = torch.from_numpy(rng.normal(3, rng.stream_id("hilo.prefix"), (4, m.dims.vision_width), 0.0, 0.05)).cuda()
+    t16, t32 = m.visual.tower, twin.visual.tower
+    for pf in (None, prefix):
+        e32 = _enc(t32, x, 96, pf)
+        plain = _enc(t16, x, big, pf)
+        hl = _enc(t16, x, big, pf, hilo=True)
+        hl_small = _enc(t16, x, small, pf, hilo=True)
+        assert torch.equal(hl, hl_small), "a compensated-stream row depends on its chunk / kernel family"
+        assert torch.equal(plain, _enc(t16, x, small, pf)), "a plain-stream row depends on its chunk"
+        d_plain, d_hl = _dir_err(plain, e32), _dir_err(hl, e32)
+        print(f"{name} prefix={pf is not None}: direction error vs the f32 twin rms plain {d_plain.pow(2).mean().sqrt():.2e} / hilo {d_hl.pow(2).mean().sqrt():.2e}, "
+              f"max {d_plain.max():.2e} / {d_hl.max():.2e}")
+        assert d_hl.pow(2).mean().sqrt() <= 0.5 * d_plain.pow(2).mean().sqrt()
+        assert d_hl.max() <= 0.7 * d_plain.max()
+        assert not torch.equal(hl, plain)
+
+
+def test_compensated_stream_is_refused_where_it_does_not_apply():
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, native
+    m, _ = clip.load("small", device="cuda")
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    t32 = m.exact_twin().visual.tower
+    out = _enc(t32, x, 4, hilo=True)           # the host layer only sets the flag on f16 towers: an f32 tower is encoded as ever
+    assert torch.equal(out, _enc(t32, x, 4))
+    # through the C ABI directly: train-mode + compensated stream is an argument error
+    from ctypes import byref, c_size_t, c_uint64, c_void_p
+    t = m.visual.tower
+    lib = native.lib()
+    nbytes = c_size_t()
+    native.check(lib.grip_workspace_bytes(t.handle, 4, 0, 1, 0, byref(nbytes)))
+    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device="cuda")
+    p = (ws.data_ptr() + 255) // 256 * 256
+    e = torch.empty(4, t.embed_dim, device="cuda")
+    gen = c_uint64()
+    rc = lib.grip_vit_forward(t.handle, c_void_p(x.data_ptr()), 0, None, 0, 4, c_void_p(e.data_ptr()), c_void_p(p), nbytes.value,
+                              native.FWD_TRAIN | native.FWD_STREAM_HILO, byref(gen), c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"STREAM_HILO" in lib.grip_last_error()
+
+
+def test_identical_lists_screen_with_the_compensated_stream(monkeypatch):
+    """pseudolabels.identical_lists screens in the compensated form by default: the lists are the exact mode's and the measured bound of the screen is
+    at most half the plain stream's on the same pool."""
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, engine, pseudolabels as pl
+    from grip_amd.data.synthetic import pool_paths, structured_images
+    m, _ = clip.load("ViT-B/16", device="cuda")
+    twin = m.exact_twin()
+    n, C, k = 1536, 24, 8
+    x = torch.cat([structured_images(5, lo, lo + 96, 224) for lo in range(0, n, 96)]).cuda()
+    tok = clip.tokenize([f"a photo of a thing number {i}" for i in range(C)]).cuda()
+    paths, labels = pool_paths(n), list(range(C))
+    with torch.no_grad():
+        txt = twin.encode_text(tok)
+        e32 = pl.encode_pool(twin.visual.tower, x, chunk=256)
+    _, p32, _, a32 = engine.cosine_head(e32, txt, 100.0)
+    want = pl.leaderboard(p32.cpu().numpy(), a32.cpu().numpy(), paths, labels, k)
+    bounds = {}
+    for form in ("hilo", "f16"):
+        monkeypatch.setenv("GRIP_SCREEN_STREAM", form)
+        got = pl.identical_lists(m.visual.tower, twin.visual.tower, x, txt, 100.0, paths, labels, k, chunk=256)
+        st = pl.LAST_REFINE_STATS
+        assert (list(got[0]), list(got[1])) == (list(want[0]), list(want[1])), form
+        bounds[form] = (st["eps"], st["rows_refined"])
+        print(f"screen stream {form}: bound {st['eps']:.2e}, {st['rows_refined']} of {n} rows re-encoded")
+    assert bounds["hilo"][0] <= 0.5 * bounds["f16"][0] and bounds["hilo"][1] <= bounds["f16"][1]

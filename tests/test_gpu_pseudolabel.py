@@ -35,13 +35,9 @@ def _structured_images(n, res, seed):
 def _oracle_lists(name, images, paths, classnames, label_to_idx, k, template):
     """The reference algorithm on the CPU oracle: per-image clip_model(image, text) -> softmax ->
     argmax(probs) -> literal leaderboard (utils/clip_pseudolabels.py:24-112)."""
-    from conftest import oracle_clip
-    from oracle import leaderboard as LB, wrappers as W
-    oc = oracle_clip()
-    om, _ = oc.load(name)
-    text = oc.tokenize(W.zero_shot_prompt_strings(template, classnames))
-    with torch.no_grad():
-        logits = torch.cat([om(images[i:i + 1], text)[0] for i in range(images.shape[0])])
+    from conftest import oracle_logits
+    from oracle import leaderboard as LB
+    logits = oracle_logits(name, images, template, classnames)
     probs, pred = LB.softmax_argmax(logits.numpy())
     return LB.leaderboard_scan(probs, pred, paths, [label_to_idx[c] for c in classnames], k), probs
 

@@ -227,3 +227,69 @@ def test_long_sequences_keep_the_f32_attention_with_split_output():
     assert ((_unsplit(out, B * S, D) - ref).abs().max() / ref.abs().max()).item() <= 2e-6
     with pytest.raises(native.GripError):
         native.check(lib.grip_debug_attention_split(_p(qkv), _p(out), B, S, H, 0, 1, _stream()))
+
+
+# ------------------------------------------------------------------------------------------ weights that are f16 numbers (r06: GemmArgs::w_exact)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (3408, 2304, 768), (5000, 768, 3072), (1000, 3072, 768)])
+def test_split_gemm_with_f16_exact_weights_drops_the_w_lo_product(M, N, K):
+    """Published CLIP checkpoints hold fp16 weights (the reference's CPU path computes in fp32 on those values cast up, methods/clip_baseline.py:39-41):
+    W's lo parts are all zero, the kernel forms a_hi w + a_lo w -- two MFMA passes instead of three -- and the result is as close to the float64
+    product as the three-pass form's on general weights.  The same weights pushed off the grid take the three-pass kernel."""
+    native, lib = _lib()
+    g = torch.Generator(device="cuda").manual_seed(M + 7 * N + K)
+    Mp = (M + 255) // 256 * 256
+    A = torch.randn(Mp, K, device="cuda", generator=g) * torch.exp(torch.randn(1, K, device="cuda", generator=g) * 0.7)
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half().float()
+    bias = torch.randn(N, device="cuda", generator=g)
+    a_s, w_s = torch.empty(Mp * K, device="cuda"), torch.empty(N * K, device="cuda")
+    ref = A[:M].double() @ W.double().t()
+    mag = A[:M].double().abs() @ W.double().abs().t()
+    floor = 3.1e-8 * W.double().abs().sum(1)[None, :]
+    out = torch.full((M, N), 7.0, device="cuda")
+    native.check(lib.grip_debug_gemm_split(0, _p(A), _p(W), M, N, K, None, None, _p(out), _p(a_s), _p(w_s), Mp, _stream()))
+    assert lib.grip_debug_split_last_wlo() == 0                      # the two-pass kernel ran
+    v = w_s.view(torch.float16).reshape(N, K // 32, 2, 32)
+    assert (v[:, :, 1] == 0).all()                                   # ... because every lo part of W is zero
+    err = (((out.double() - ref).abs() - floor).clamp_min(0) / mag).max().item()
+    assert err <= 4e-7, err
+    assert ((out.double() - ref).norm(dim=1) / ref.norm(dim=1)).max().item() <= 1e-6
+    h = torch.zeros(M * N, device="cuda")
+    native.check(lib.grip_debug_gemm_split(2, _p(A), _p(W), M, N, K, _p(bias), None, _p(h), _p(a_s), _p(w_s), Mp, _stream()))
+    want = quick_gelu(ref + bias.double())
+    assert (((_unsplit(h, M, N) - want).abs() - floor).clamp_min(0) / (mag + bias.double().abs() + 0.1 + want.abs())).max().item() <= 8e-7
+    W2 = W * (1 + 2.0 ** -13)                                        # off the grid: the lo parts are needed again
+    out2 = torch.empty(M, N, device="cuda")
+    native.check(lib.grip_debug_gemm_split(0, _p(A), _p(W2), M, N, K, None, None, _p(out2), _p(a_s), _p(w_s), Mp, _stream()))
+    assert lib.grip_debug_split_last_wlo() == 1
+    ref2 = A[:M].double() @ W2.double().t()
+    assert (((out2.double() - ref2).abs() - floor).clamp_min(0) / mag).max().item() <= 4e-7
+
+
+def test_split_tower_on_an_fp16_checkpoint_tracks_the_exact_twin():
+    """clip.load(..., fp16_checkpoint=True): synthetic weights rounded to f16 numbers as a published checkpoint holds them.  The split twin takes
+    the two-pass GEMMs (grip_tower_finalize found no non-zero lo part) and stays as close to the f32 twin as on general weights; the f16 tower
+    rounds no weight any more and moves closer to the twin than on the un-rounded init."""
+    import grip_amd  # noqa: F401
+    from grip_amd import clip, pseudolabels as pl
+    from grip_amd.data.synthetic import structured_images
+    native, lib = _lib()
+    x = structured_images(77, 0, 48, 224).cuda()
+    devs = {}
+    for grid in (False, True):
+        m, _ = clip.load("ViT-B/16", device="cuda", fp16_checkpoint=grid)
+        twin, split = m.exact_twin(), m.split_twin()
+        with torch.no_grad():
+            e32 = pl.encode_pool(twin.visual.tower, x, chunk=32)
+            es = pl.encode_pool(split.visual.tower, x, chunk=32)
+            assert lib.grip_debug_split_last_wlo() == (0 if grid else 1)
+            es2 = pl.encode_pool(split.visual.tower, x, chunk=7)
+            e16 = pl.encode_pool(m.visual.tower, x, chunk=32)
+        assert torch.equal(es, es2)
+        r_s = ((es - e32).norm(dim=1) / e32.norm(dim=1)).max().item()
+        r_16 = ((e16 - e32).norm(dim=1) / e32.norm(dim=1)).max().item()
+        print(f"fp16_checkpoint={grid}: embedding rel L2 split {r_s:.2e} / f16 {r_16:.2e}")
+        assert r_s <= 5e-6
+        devs[grid] = r_16
+        del m, twin, split
+        torch.cuda.empty_cache()
+    assert devs[True] < devs[False]
