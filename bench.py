@@ -151,7 +151,9 @@ class Loop:
             t0 = self.tick()
             txt = self.twin.encode_text(self.zs_tokens)
             local = torch.empty(a.pool, self.d.embed_dim, dtype=torch.float32, device=self.device)
-            self.m.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk, streams=streams, hilo=pl.screen_stream() == "hilo")
+            key = ("bench", id(self.pool), a.pool, self.C)
+            stream = pl.screen_stream(key)
+            self.m.visual.tower.encode_chunks(self.pool, local, 0, a.pool, a.chunk, streams=streams, hilo=stream == "hilo")
             t1 = self.tick()
             emb = gdist.allgather_rows(local, self.n_total, a.pool, tag="pool_embeddings")
             t2 = self.tick()
@@ -177,6 +179,7 @@ class Loop:
 
             img, cls, self.refine_stats = pl.refine_scan(probs_h, pred_h, self.ranks, self.k, rows_through(self.twin.visual.tower, "exact", a.exact_chunk),
                                                          mid_rows=rows_through(self.split.visual.tower, "split", a.exact_chunk) if self.split is not None else None)
+            pl.note_screen_bound(key, stream, self.refine_stats)
             t3 = self.tick()
         st["encode_f16"] += t1 - t0
         st["allgather"] += t2 - t1
@@ -522,7 +525,8 @@ def refine_summary(rs):
     return {"rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"], "rows_reencoded_exactly": rs["rows_exact"], "tiers": rs["tiers"],
             "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1), "nonfinite_screen_rows": rs.get("nonfinite_screen_rows", 0),
             "calibration_rows": rs["calibration_rows"], "rounds": rs["rounds"], "scans": rs["scans"], "rows_per_round": rs["refined_per_round"],
-            "tier_calls": rs["tier_calls"], "bound_form": rs["bound_form"], "bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "bound_split_f16": rs["eps_mid"],
+            "tier_calls": rs["tier_calls"], "screen_stream": rs.get("screen_stream"), "screen_stream_next_pass": rs.get("screen_stream_next_pass"),
+            "bound_form": rs["bound_form"], "bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "bound_split_f16": rs["eps_mid"],
             "largest_deviation_seen_split_f16": rs["max_deviation_mid"], "safety": rs["safety"], "safety_split_f16": rs.get("safety_mid"),
             "audit_rows": rs["audit_rows"], "audit_board_rows": rs["audit_board_rows"], "audit_max_deviation": rs["audit_max_deviation"],
             "audit_widened_the_bound": rs["audit_widened"], "audits": rs["audits"], "audit_rows_split_f16": rs.get("audit_mid_rows", 0),
@@ -639,7 +643,7 @@ def peaked_pool_block(loop, kind):
                 "identical_images_per_sec": n / dt, "exact_mode_images_per_sec": n / t_exact,
                 "logit_spread_max_minus_median": float(np.mean(lg.max(1) - np.median(lg, 1))), "mean_top_probability": float(p32h.max(1).mean()),
                 "distinct_argmax_classes": int(len(np.unique(a32h))), "text_features_cosine_with_the_pool_mean": common,
-                "screen_stream": pl.screen_stream(), "refine": refine_summary(rs),
+"refine": refine_summary(rs),
                 "model": ("ViT-B/16 synthetic-stress (weights.stress_state_dict): four residual-stream channels at x ~ +200 on every token (LayerNorm gains compensated; fp32 vs fp64 "
                           "oracle 1e-7), last block scaled so that one stream channel of the CLS row leaves the f16 range on ~ 1/5 of the images; text features = mean-removed "
                           "prototypes of the pool's own embeddings") if kind == "stress" else
@@ -889,7 +893,7 @@ def main():
                    "last_block_rows_only": f_img_x != F_IMG,
                    "weights": "synthetic seeded init" + (", matrix weights rounded to f16 numbers as in the published fp16 checkpoints (weights.on_f16_grid)"
                                                          if os.environ.get("GRIP_SYNTHETIC_FP16") == "1" else ""),
-                   "screen_stream": pl.screen_stream() if args.mode == "identical" else None,
+                   "screen_stream": None if rs is None else f"{os.environ.get('GRIP_SCREEN_STREAM', 'auto')}: the last timed pass screened with the {rs.get('screen_stream')} residual stream",
                    "train_sharding": "the product trainer's sharding (dist.rank_batches = accelerate's even batches): batch j of the selected pairs in list order goes to rank j % N, "
                                      "batch 16 per rank, tail padded from the start; the selected images are all-gathered once per pass (each rank contributes its shard's); "
                                      "prompt gradients are mean-all-reduced every step -- not one global batch split over ranks",

@@ -196,6 +196,7 @@ struct Workspace {  // carve of the caller's buffer for one (batch, n_prefix, tr
     half_t* row_datt = nullptr;   // [Bp, d]
     float* stat_part = nullptr;// [d/64, M, 2] partial row sums emitted by the residual GEMM epilogues (f16 towers)
     float* rowstat = nullptr;  // [Mp, 2] (mean, rstd) of the residual stream's rows, consumed by the LayerNorm-folded GEMMs
+    half_t* row_x_lo = nullptr;   // ... and of the last block's compact read rows
     half_t* x_lo = nullptr;    // inference, f16 towers: the lo parts of the stream when the forward runs with GRIP_FWD_STREAM_HILO (GemmArgs::resid_lo)
     int hilo = 0;              // ... and whether this forward does
     // train-mode saves, one per layer (x_in has layers+1 entries)
@@ -293,6 +294,7 @@ static int carve(const grip_tower* t, int batch, int P, int train, char* base, W
     w.rows_last = train && !t->f32 && !shared && !last_block_full();
     if (!train || w.rows_last) {       // compact [batch, .] buffers of a last block that runs for the read rows only (f32 / split towers: 4-byte elements)
         w.row_x = (half_t*)take(Bp * d * es);
+        if (!train && !t->f32) w.row_x_lo = (half_t*)take(Bp * d * 2);
         w.row_att = (half_t*)take(Bp * d * es);
         w.row_xn = (half_t*)take(Bp * d * es);
         w.row_h = (half_t*)take(Bp * 4 * d * es);
@@ -489,6 +491,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             a.rowstat = w.rowstat; a.out = w.qkv + d; a.ldc = 3 * d;
             RUN(launch_gemm(EPI_LNFOLD_F16, a, s));
             RUN(launch_gather_rows(x, read_rows, w.S, w.row_x, w.batch, d, s));
+            if (hilo) RUN(launch_gather_rows(w.x_lo, read_rows, w.S, w.row_x_lo, w.batch, d, s));      // the read rows keep their compensation through the block's two adds
             RUN(launch_layernorm_f16(w.row_x, F + lw.ln1_g, F + lw.ln1_b, w.row_xn, 0, w.batch, d, s));
             a = GemmArgs{};
             a.A = w.row_xn; a.W = t->w16 + lw.in_w; a.M = w.batch; a.m_pad = round_up64(w.batch, 256); a.N = d; a.K = d; a.bias = F + lw.in_b; a.out = w.row_h; a.ldc = d;
@@ -497,6 +500,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             const int64_t Bp = round_up64(w.batch, 256);
             a = GemmArgs{};
             a.A = w.row_att; a.W = t->w16 + lw.out_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = d; a.bias = F + lw.out_b; a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
+            if (hilo) { a.resid_lo = w.row_x_lo; a.stat_part = w.stat_part; }      // (the compensated form lives in the statistics-carrying epilogue; nobody reads these sums)
             RUN(launch_gemm(EPI_BIAS_RESID, a, s));
             RUN(launch_layernorm_f16(w.row_x, F + lw.ln2_g, F + lw.ln2_b, w.row_xn, 0, w.batch, d, s));
             a = GemmArgs{};
@@ -504,6 +508,7 @@ static int run_blocks(grip_tower* t, Workspace& w, resid_t* x0, int causal, cons
             RUN(launch_gemm(EPI_BIAS_GELU_F16, a, s));
             a = GemmArgs{};
             a.A = w.row_h; a.W = t->w16 + lw.proj_w; a.M = w.batch; a.m_pad = Bp; a.N = d; a.K = 4 * d; a.bias = F + lw.proj_b; a.resid = w.row_x; a.out = w.row_x; a.ldc = d;
+            if (hilo) { a.resid_lo = w.row_x_lo; a.stat_part = w.stat_part; }
             RUN(launch_gemm(EPI_BIAS_RESID, a, s));
             x = w.row_x;
             *compact = true;

@@ -80,15 +80,36 @@ def path_ranks(paths):
     return r
 
 
-def screen_stream():
-    """Residual stream of the f16 tower when it SCREENS a pool for identical_lists: "hilo" (default) -- a compensated pair of f16 numbers per element
+SCREEN_HILO_ABOVE = 0.04    # bound of the PLAIN-stream screen (log-odds form) above which the compensated stream pays for its +6.6 % encode time (r06 bench pools: the
+                            # near-uniform timed pool, bound 0.025: 0.08 s of re-encodes saved per 50 000 images against 0.115 s of encode; the realistic pool, 0.06:
+                            # the other way round; the stress model, 0.8: 11.3k against 9.0k img/s)
+SCREEN_HILO_GAIN = 2.2      # measured ratio of the two screens' bounds on the same pool (tests/test_gpu_hilo.py)
+_SCREEN_CHOICE = {}         # pool key -> stream the NEXT pass over it screens with (what its last pass measured)
+
+
+def screen_stream(key=None):
+    """Residual stream of the f16 tower when it SCREENS a pool for identical_lists.  "hilo": a compensated pair of f16 numbers per element
     (GRIP_FWD_STREAM_HILO: the 24 roundings of the stream of a ViT-B/16 image no longer accumulate; the embeddings' direction error against the f32
-    tower drops 2.5 - 3x, and the measured bound of the screen with it) -- or "f16" (rounds 1-5: the plain stream).  Only the screen: train-mode
-    forwards, evaluation and the f16 MODE keep the f16 stream the reference's GPU path has.  $GRIP_SCREEN_STREAM."""
-    v = os.environ.get("GRIP_SCREEN_STREAM", "hilo")
-    if v not in ("hilo", "f16"):
-        raise ValueError(f"GRIP_SCREEN_STREAM={v!r}: expected 'hilo' or 'f16'")
-    return v
+    tower and the measured bound of the screen drop 2.2 - 2.5x, for +6.6 % encode time).  "f16": the plain stream (rounds 1-5).  $GRIP_SCREEN_STREAM =
+    "auto" (default) picks per pool: the first pass over a pool screens compensated (the safe side: it never costs more than 6.6 %), every pass records its
+    bound (note_screen_bound), and the next pass over the same pool -- GRIP re-labels one pool every iteration, pseudo_iterative.py:62-125 -- screens plain
+    where the plain screen's bound stays below SCREEN_HILO_ABOVE.  The lists do not depend on the choice (both screens are certified against the same
+    exact values); only the number of re-encoded rows does.  Train-mode forwards, evaluation and the f16 MODE always keep the plain stream."""
+    v = os.environ.get("GRIP_SCREEN_STREAM", "auto")
+    if v not in ("auto", "hilo", "f16"):
+        raise ValueError(f"GRIP_SCREEN_STREAM={v!r}: expected 'auto', 'hilo' or 'f16'")
+    return _SCREEN_CHOICE.get(key, "hilo") if v == "auto" else v
+
+
+def note_screen_bound(key, stream, stats):
+    """Record what a pass measured, for screen_stream("auto"): the plain screen's bound (a compensated pass's bound x SCREEN_HILO_GAIN) decides the next
+    pass's stream.  The statistics are identical on every rank, so every rank decides alike."""
+    if key is None or not stats or stats.get("bound_form") != "odds" or stats.get("rows", 0) == 0:
+        return
+    plain = stats["eps"] * (SCREEN_HILO_GAIN if stream == "hilo" else 1.0)
+    _SCREEN_CHOICE[key] = "hilo" if (plain > SCREEN_HILO_ABOVE or stats.get("nonfinite_screen_rows", 0)) else "f16"
+    stats["screen_stream"] = stream
+    stats["screen_stream_next_pass"] = _SCREEN_CHOICE[key]
 
 
 @torch.no_grad()
@@ -96,12 +117,14 @@ def encode_pool(visual_tower, images, chunk=880, prefix=None, out=None, screen=F
     """Encode an ordered pool.  `images` is a tensor [N,3,R,R] (any device) or a callable
     (lo, hi) -> tensor for that slice.  With torch.distributed initialised the pool is sharded
     contiguously and the embeddings are all-gathered; returns [N, E] f32 on the device.
-    screen=True: this is the screen of a screen-and-refine pass (screen_stream() picks the tower's stream form)."""
+    screen: False, or the stream form ("hilo" / "f16") of a screen-and-refine pass's screen; True = screen_stream() without a pool history."""
+    if screen is True:
+        screen = screen_stream()
     n = images.shape[0] if torch.is_tensor(images) else images.n
     lo, hi, per = gdist.shard_range(n)
     dev = visual_tower.device
     local = torch.empty(max(hi - lo, 0), visual_tower.embed_dim, dtype=torch.float32, device=dev)
-    visual_tower.encode_chunks(images, local, lo, hi, chunk, prefix, hilo=screen and screen_stream() == "hilo")
+    visual_tower.encode_chunks(images, local, lo, hi, chunk, prefix, hilo=screen == "hilo")
     return gdist.allgather_rows(local, n, per, tag="pool_embeddings")
 
 
@@ -521,7 +544,9 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
         _, _, LAST_REFINE_STATS = refine_scan(np.empty((0, max(len(class_labels), 1)), np.float32), np.empty(0, np.int32), np.empty(0, np.int64), k, None)
         LAST_REFINE_STATS["rows_refined_this_rank"] = 0
         return [], []
-    emb = emb16 if emb16 is not None else encode_pool(visual16, images, chunk=chunk, prefix=prefix, screen=True)
+    key = (id(visual16), n, len(class_labels))        # the pool as far as the screen's choice of stream goes (same tower, same size, same class count)
+    stream = screen_stream(key) if emb16 is None else None
+    emb = emb16 if emb16 is not None else encode_pool(visual16, images, chunk=chunk, prefix=prefix, screen=stream)
     dev = emb.device
     _, probs, am_l, am_p = engine.cosine_head(emb, txt_exact, scale)
     probs_h = probs.cpu().numpy()
@@ -545,6 +570,8 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
                                   mid_rows=rows_through(visual_mid, "mid", mid_chunk) if visual_mid is not None else None)
     stats["rows_refined_this_rank"] = encoded["exact"] + encoded["mid"]
     stats["rows_exact_this_rank"], stats["rows_mid_this_rank"] = encoded["exact"], encoded["mid"]
+    if stream is not None:
+        note_screen_bound(key, stream, stats)
     LAST_REFINE_STATS = stats
     return [paths[i] for i in img], [class_labels[int(c)] for c in cls]
 

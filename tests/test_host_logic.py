@@ -354,3 +354,34 @@ def test_stress_weights_are_well_conditioned_and_keep_gemm_operands_in_f16_range
         OM.LayerNorm.forward = keep
     cos = torch.nn.functional.cosine_similarity(e32, e64, dim=1)
     assert float((1 - cos).max()) < 1e-5, float((1 - cos).max())
+
+
+def test_screen_stream_is_picked_per_pool_from_the_last_pass(monkeypatch):
+    """pseudolabels.screen_stream("auto"): the first pass over a pool screens with the compensated stream; a pass whose (plain-equivalent) bound is small
+    sends the next pass over the SAME pool to the plain stream, a large one (or a non-finite screen row) back to the compensated one; explicit settings
+    win; other pools are not affected."""
+    import grip_amd  # noqa: F401
+    from grip_amd import pseudolabels as pl
+    monkeypatch.delenv("GRIP_SCREEN_STREAM", raising=False)
+    pl._SCREEN_CHOICE.clear()
+    key, other = ("tower", 50000, 102), ("tower", 2000, 10)
+    assert pl.screen_stream(key) == "hilo" and pl.screen_stream() == "hilo"
+    st = {"bound_form": "odds", "rows": 50000, "eps": 0.011, "nonfinite_screen_rows": 0}
+    pl.note_screen_bound(key, "hilo", st)                         # 0.011 x 2.2 = 0.024 < 0.04: the plain screen is cheap enough here
+    assert pl.screen_stream(key) == "f16" and st["screen_stream"] == "hilo" and st["screen_stream_next_pass"] == "f16"
+    assert pl.screen_stream(other) == "hilo"
+    pl.note_screen_bound(key, "f16", dict(st, eps=0.025))
+    assert pl.screen_stream(key) == "f16"
+    pl.note_screen_bound(key, "f16", dict(st, eps=0.07))          # the prompts moved: the pool became sensitive
+    assert pl.screen_stream(key) == "hilo"
+    pl.note_screen_bound(key, "hilo", dict(st, eps=0.011, nonfinite_screen_rows=3))
+    assert pl.screen_stream(key) == "hilo"                        # f16 overflows: the plain stream would not help
+    pl.note_screen_bound(key, "hilo", dict(st, bound_form="relative"))      # (not comparable: left alone)
+    assert pl.screen_stream(key) == "hilo"
+    monkeypatch.setenv("GRIP_SCREEN_STREAM", "f16")
+    assert pl.screen_stream(key) == "f16" and pl.screen_stream(other) == "f16"
+    monkeypatch.setenv("GRIP_SCREEN_STREAM", "bogus")
+    import pytest
+    with pytest.raises(ValueError):
+        pl.screen_stream(key)
+    pl._SCREEN_CHOICE.clear()
