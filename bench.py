@@ -164,18 +164,11 @@ class Loop:
             t_tier = {"exact": 0.0, "split": 0.0}
 
             def rows_through(tower, tier, chunk):
-                def rows(idx):
-                    ta = time.perf_counter()
-                    mine = torch.from_numpy(idx[(idx >= lo) & (idx < lo + a.pool)] - lo).to(self.device)
-                    emb_rows = torch.empty(len(mine), self.d.embed_dim, dtype=torch.float32, device=self.device)
-                    if len(mine):
-                        tower.encode_chunks(lambda s, e: self.pool[mine[s:e]], emb_rows, 0, len(mine), chunk, streams=pl.tier_streams())
-                    emb_rows = gdist.allgather_selected(emb_rows, idx, self.n_total, tag="refined_rows")
-                    _, p, _, ap = engine.cosine_head(emb_rows, txt, scale)
-                    out = p.cpu().numpy(), ap.cpu().numpy()
-                    t_tier[tier] += time.perf_counter() - ta
-                    return out
-                return rows
+                # (pseudolabels.tier_rows: the product's tier callback; the tiers of one refinement step run side by side on their own streams, so the
+                # per-tier seconds below are host-side waits and may overlap)
+                def spent(dt):
+                    t_tier[tier] += dt
+                return pl.tier_rows(tower, lambda rows: self.pool[torch.from_numpy(rows - lo).to(self.device)], txt, scale, self.n_total, lo, lo + a.pool, chunk, timer=spent)
 
             img, cls, self.refine_stats = pl.refine_scan(probs_h, pred_h, self.ranks, self.k, rows_through(self.twin.visual.tower, "exact", a.exact_chunk),
                                                          mid_rows=rows_through(self.split.visual.tower, "split", a.exact_chunk) if self.split is not None else None)

@@ -138,6 +138,8 @@ def leaderboard(probs, pred, paths, class_labels, k):
 
 # ------------------------------------------------------------------------------------------ screen and refine
 REFINE_CALIB_ROWS = 256     # rows re-encoded exactly up front to measure the cheaper tiers' deviation on THIS pool
+REFINE_MIN_SAMPLE = 64      # ... and never fewer than this (calibration and audit alike; 16 until r06: on a 300-image pool the 18 calibration rows understated the
+                            # log-odds bound of the compensated screen -- tighter than any bound before it -- and one pair of a board came back transposed)
 REFINE_SAFETY = 2.0         # bound = safety x the largest deviation seen on any row re-encoded so far (it only ever grows)
 REFINE_SAFETY_MID = 4.0     # the same for the middle tier: its bound rests on a quarter of the calibration rows (an f32 row costs 2.5 split-f16 ones), so it is
                             # given twice the margin instead (8 x was measured: 293 instead of 222 f32 rows per pass on the bench pool, +0.025 s) -- at 1e-5-sized deviations the extra band holds a handful of rows
@@ -145,6 +147,8 @@ REFINE_ESCALATE_AFTER = 8   # rounds after which whatever is still un-refined mo
 REFINE_AUDIT_ROWS = 256     # un-refined rows re-encoded AFTER the scan certified its lists, to check the bound they were trusted to ($GRIP_REFINE_AUDIT)
 REFINE_AUDIT_ROWS_LARGE = 1024   # ... for pools of REFINE_AUDIT_LARGE_POOL rows and more (what the lists take on trust there rests on a four times larger hold-out)
 REFINE_AUDIT_LARGE_POOL = 50000
+REFINE_AUDIT_MID_ROWS = 32  # rows the MIDDLE tier is trusted on that an audit sends through the exact tower (its deviations are f32-rounding-sized and tightly
+                            # distributed; every row the scan sends on to the exact tower adds to the sample; an f32 row costs 2.5 split-f16 ones)
 REFINE_MAX_AUDITS = 4       # audits that may each widen the bound before everything left is simply re-encoded
 REFINE_ABS_EPS = 1e-30      # absolute slack of an un-refined probability: below this a softmax output has no relative accuracy (denormals, 0)
 _EPS_CAP = 9e5              # grip_leaderboard_scan_bounded takes relative bounds below 1e6 (a bound >= 1 already means "anything below")
@@ -281,7 +285,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     sits at level 0 (screen), 1 (middle) or 2 (exact, final).  Level-0 / level-1 values are trusted only up to a relative bound
     eps[level] = safety x (largest deviation seen so far between a value of that level and the better value that later replaced it),
     plus an absolute slack `abs_eps` for values in the denormal range; the bounds start from `calib` rows -- at most 1/16 of the pool,
-    at least 16 -- spread evenly over it: all of them through the next tier up, every fourth through the exact tower as well when there
+    at least REFINE_MIN_SAMPLE = 64 -- spread evenly over it: all of them through the next tier up, every fourth through the exact tower as well when there
     is a middle tier.  grip_leaderboard_scan_bounded marks every non-final row
     that takes part in a comparison its bound cannot decide; marked rows move up one tier and the scan repeats until nothing is
     marked and no bound has moved: the lists are then certified, decision by decision, to be those of the scan over the all-f32
@@ -308,18 +312,30 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     cap = _EPS_CAP if form == "relative" else _DELTA_CAP
     audit = audit_rows_default(n) if audit is None else int(audit)
     if audit > 0:
-        audit = min(n, max(16, min(audit, n // 16)))       # like the calibration sample: at most 1/16 of the pool, at least 16 rows
+        audit = min(n, max(REFINE_MIN_SAMPLE, min(audit, n // 16)))       # like the calibration sample: at most 1/16 of the pool, at least REFINE_MIN_SAMPLE rows
     level = np.zeros(n, dtype=np.int8)
     dev = [0.0, 0.0]                # largest deviation seen of a level-0 / level-1 value from the better value that replaced it
     n_mid = n_exact = 0
 
-    def to_exact(idx, measure=True):
+    def submit(fn, idx):
+        """Start a tier's re-encode of rows `idx`: tier callbacks with a `.submit(idx)` (the GPU tiers: work enqueued on the tier's own stream, nothing
+        waited for) return a callable that waits and hands back (probs, argmax); plain callbacks run here and now.  Two tiers submitted back to back run side
+        by side on the GPU -- the f32 tower's few hundred rows per pass no longer run alone at a third of its rate (r06, VERDICT r5 #4)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size == 0:
+            return None
+        stats["tier_calls"] += 1
+        if hasattr(fn, "submit"):
+            return fn.submit(idx)
+        out = fn(idx)
+        return lambda: out
+
+    def to_exact(idx, measure=True, pending=None):
         nonlocal n_exact
         idx = np.asarray(idx, dtype=np.int64)
         if idx.size == 0:
             return
-        p32, a32 = exact_rows(idx)
-        stats["tier_calls"] += 1
+        p32, a32 = (pending or submit(exact_rows, idx))()
         for lv in (0, 1):
             sel = (level[idx] == lv) & np.isfinite(probs[idx]).all(axis=1)       # (a non-finite row says nothing about the tier's accuracy)
             if measure and sel.any():
@@ -329,13 +345,12 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         level[idx] = 2
         n_exact += idx.size
 
-    def to_mid(idx):
+    def to_mid(idx, pending=None):
         nonlocal n_mid
         idx = np.asarray(idx, dtype=np.int64)
         if idx.size == 0:
             return
-        pm, am = mid_rows(idx)
-        stats["tier_calls"] += 1
+        pm, am = (pending or submit(mid_rows, idx))()
         n_mid += idx.size           # (rows the tier ENCODED: an overflow inside it is paid for all the same)
         bad = ~np.isfinite(pm).all(axis=1)
         if bad.any():       # an overflow inside the cheaper tower (f16 range): those rows go straight to the exact tower
@@ -358,8 +373,9 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         idx = np.asarray(idx, dtype=np.int64)
         lo = idx[level[idx] == 0] if mid_rows is not None else idx[:0]
         hi = idx[level[idx] == 1] if mid_rows is not None else idx
-        to_mid(lo)
-        to_exact(hi)
+        h_lo, h_hi = submit(mid_rows, lo), submit(exact_rows, hi)        # both tiers in flight before either is waited for
+        to_mid(lo, pending=h_lo)
+        to_exact(hi, pending=h_hi)
 
     def bound(lv):
         return min((safety if lv == 0 else max(safety, REFINE_SAFETY_MID)) * dev[lv], cap)
@@ -377,10 +393,10 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         to_mid(broken)                  # overflows on itself goes on to the exact tower inside to_mid); r05 sent them to the exact tower directly
     else:
         to_exact(broken, measure=False)
-    # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than 16 (a bound from one or two rows is no bound) -- spread evenly over
+    # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than REFINE_MIN_SAMPLE (a bound from a handful of rows is no bound) -- spread evenly over
     # the rows the screen is still trusted on (a row it overflowed on measures nothing; with no such rows: over the pool, as before)
     live = np.flatnonzero(level == 0)
-    want = min(live.size, max(16, min(calib, n // 16)))
+    want = min(live.size, max(REFINE_MIN_SAMPLE, min(calib, n // 16)))
     cal = live[np.unique(np.linspace(0, live.size - 1, want).astype(np.int64))] if want else live
     if cal.size == 0:
         pass                            # every row is final already (an all-non-finite screen): nothing to calibrate, nothing left to trust
@@ -390,10 +406,11 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         # distributed (three f16 products with f32 accumulation: ~3 x 2^-23 per term), the rows the scan sends on to the exact tower and the
         # audit keep adding to the sample, and an f32 row costs 2.5x a split-f16 one.
         cal_x = cal[:: max(1, len(cal) // max(16, len(cal) // 4))]
-        pm_x, _ = mid_rows(cal_x)
+        rest = np.setdiff1d(cal, cal_x)
+        h_mid, h_ex, h_rest = submit(mid_rows, cal_x), submit(exact_rows, cal_x), submit(mid_rows, rest)     # the three calibration encodes side by side
+        pm_x, _ = h_mid()
         n_mid += cal_x.size
-        p32_x, a32_x = exact_rows(cal_x)
-        stats["tier_calls"] += 2
+        p32_x, a32_x = h_ex()
         n_exact += cal_x.size
         fin = np.isfinite(pm_x).all(axis=1)            # (a middle-tier overflow measures nothing either; the row is exact now anyway)
         if fin.any():
@@ -403,7 +420,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
         if fin.any():
             dev[0] = deviation(probs[cal_x[fin]], p32_x[fin], abs_eps)
         probs[cal_x], pred[cal_x], level[cal_x] = p32_x, a32_x, 2
-        to_mid(cal[level[cal] == 0])
+        to_mid(rest, pending=h_rest)
     else:
         to_exact(cal)
     stats["calibration_rows"] = int(cal.size)
@@ -441,11 +458,14 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
             sample = np.unique(np.concatenate([pick_b, pick_o]).astype(np.int64))
             before = list(dev)
             dev[0] = dev[1] = 0.0
+            h_mids = None
+            if mid_rows is not None:                        # ... and a few rows the middle tier is trusted on go through the exact tower (beside the screen's sample:
+                mids = np.flatnonzero(level == 1)           # drawn before it moves up, submitted first so that the two tiers run side by side)
+                sample_mid = np.sort(g.choice(mids, size=min(mids.size, max(min(audit // 8, REFINE_AUDIT_MID_ROWS), 1)), replace=False)) if mids.size else mids
+                h_mids = submit(exact_rows, sample_mid)
             up(sample)
-            if mid_rows is not None:                        # ... and a few rows the middle tier is trusted on go through the exact tower
-                mids = np.flatnonzero(level == 1)
-                sample_mid = np.sort(g.choice(mids, size=min(mids.size, max(audit // 8, 1)), replace=False)) if mids.size else mids
-                to_exact(sample_mid)
+            if mid_rows is not None:
+                to_exact(sample_mid, pending=h_mids)
                 stats["audit_mid_rows"] = stats.get("audit_mid_rows", 0) + int(sample_mid.size)
                 stats["audit_max_deviation_mid"] = max(stats.get("audit_max_deviation_mid", 0.0), float(dev[1]))
             seen = list(dev)
@@ -527,6 +547,46 @@ def take_images(images, idx):
     return images.take(idx)
 
 
+def tier_rows(tower, fetch, txt, scale, n, lo, hi, chunk, prefix=None, argmax_on="probs", on_rows=None, timer=None):
+    """A refinement tier as refine_scan's callback: rows(idx) -> (probs [len(idx), C], arg-max) of the global rows `idx` (ascending) re-encoded by `tower`.
+    Each rank encodes the rows of its own shard [lo, hi) -- `fetch(global_rows)` returns their images -- and one padded all-gather assembles the rest.
+    rows.submit(idx) only ENQUEUES the work, on the tier's own HIP stream, and returns the function that waits for it: two tiers submitted back to back
+    (refine_scan does that wherever their row sets are independent) share the GPU instead of taking turns at small-batch efficiency."""
+    dev = tower.device
+    side = torch.cuda.Stream(device=dev)
+
+    def submit(idx):
+        import time
+        t0 = time.perf_counter()
+        mine = idx[(idx >= lo) & (idx < hi)]
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            local = torch.empty(len(mine), tower.embed_dim, dtype=torch.float32, device=dev)
+            if len(mine):
+                tower.encode_chunks(lambda a, b: fetch(mine[a:b]), local, 0, len(mine), chunk, prefix, streams=tier_streams())
+            if on_rows is not None:
+                on_rows(len(mine))
+            got = gdist.allgather_selected(local, idx, n, tag="refined_rows")
+            _, p, al, ap = engine.cosine_head(got, txt, scale)
+            am = ap if argmax_on == "probs" else al
+        if timer is not None:
+            timer(time.perf_counter() - t0)
+
+        def result():
+            t1 = time.perf_counter()
+            side.synchronize()
+            out = p.cpu().numpy(), am.cpu().numpy()
+            if timer is not None:
+                timer(time.perf_counter() - t1)
+            return out
+        return result
+
+    def rows(idx):
+        return submit(idx)()
+    rows.submit = submit
+    return rows
+
+
 @torch.no_grad()
 def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_labels, k, chunk=880, exact_chunk=880, prefix=None,
                     argmax_on="probs", streams=2, emb16=None, visual_mid=None, mid_chunk=880):
@@ -555,16 +615,9 @@ def identical_lists(visual16, visual32, images, txt_exact, scale, paths, class_l
     encoded = {"exact": 0, "mid": 0}
 
     def rows_through(tower, tier, tier_chunk):
-        def rows(idx):
-            mine = idx[(idx >= lo) & (idx < hi)]
-            local = torch.empty(len(mine), tower.embed_dim, dtype=torch.float32, device=dev)
-            if len(mine):
-                tower.encode_chunks(lambda a, b: take_images(images, mine[a:b]), local, 0, len(mine), tier_chunk, prefix, streams=tier_streams())
-            encoded[tier] += len(mine)
-            got = gdist.allgather_selected(local, idx, n, tag="refined_rows")
-            _, p, al, ap = engine.cosine_head(got, txt_exact, scale)
-            return p.cpu().numpy(), (ap if argmax_on == "probs" else al).cpu().numpy()
-        return rows
+        def count(m):
+            encoded[tier] += m
+        return tier_rows(tower, lambda rows: take_images(images, rows), txt_exact, scale, n, lo, hi, tier_chunk, prefix, argmax_on, on_rows=count)
 
     img, cls, stats = refine_scan(probs_h, pred_h, path_ranks(paths), k, rows_through(visual32, "exact", exact_chunk),
                                   mid_rows=rows_through(visual_mid, "mid", mid_chunk) if visual_mid is not None else None)
