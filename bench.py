@@ -50,12 +50,6 @@ TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
 PEAK_CLOCK_MHZ = 2400.0  # the shader clock behind the 2.5 PFLOP/s figure
 
 
-# The bench's synthetic weights sit on the f16 grid, as the weights of every published CLIP checkpoint do (fp16 archives; the reference's CPU path computes in
-# fp32 on those values cast up): the f32 twin then multiplies exactly the numbers the f16 towers hold, as it would with real weights.  GRIP_SYNTHETIC_FP16=0:
-# the un-rounded seeded init of rounds 1-5 (the test fixtures keep it).
-os.environ.setdefault("GRIP_SYNTHETIC_FP16", "1")
-
-
 def clock_marker(label):
     """`##clock_trace <label>` on stderr for tools/clock_trace.py (GRIP_CLOCK_MARKERS=1)."""
     if os.environ.get("GRIP_CLOCK_MARKERS") == "1":
@@ -404,6 +398,11 @@ def cpu_baseline(args):
                   f"one text encode of {C} prompts {t_txt:.2f} s; oracle build {build_s:.0f} s; {threads} torch threads; wall budget {budget:.0f} s",
         "r_mode_images": n_r, "r_mode_full_calls_timed": reps,
         "b_mode_images_per_sec": b_ips, "b_mode_batches": len(t_b),
+        # the host CPUs are shared with other tenants (r04 -> r05: R-mode 0.70 -> 2.11, B-mode 30.7 -> 42.6 img/s on the same CPU model and thread count): the
+        # spread INSIDE this run, so that a reader can tell a quiet host from a busy one
+        "spread": {"r_mode_image_tower_ms_min_median_max": [float(np.min(t_img)) * 1e3, float(np.median(t_img)) * 1e3, float(np.max(t_img)) * 1e3],
+                   "r_mode_full_call_s_min_max": [float(np.min(t_full)), float(np.max(t_full))],
+                   "b_mode_images_per_sec_per_batch": [16.0 / t for t in t_b]},
     }
 
 
@@ -759,6 +758,10 @@ def main():
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                   "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:])
 
+    # The bench's synthetic weights sit on the f16 grid, as the weights of every published CLIP checkpoint do (fp16 archives; the reference's CPU path computes in
+    # fp32 on those values cast up): the f32 twin then multiplies exactly the numbers the f16 towers hold, as it would with real weights.  GRIP_SYNTHETIC_FP16=0:
+    # the un-rounded seeded init of rounds 1-5 (the test fixtures keep it).  Set here, not at import: tests and tools import this module for its helpers.
+    os.environ.setdefault("GRIP_SYNTHETIC_FP16", "1")
     rank, ws = gdist.init_from_env()
     if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")

@@ -138,8 +138,8 @@ def leaderboard(probs, pred, paths, class_labels, k):
 
 # ------------------------------------------------------------------------------------------ screen and refine
 REFINE_CALIB_ROWS = 256     # rows re-encoded exactly up front to measure the cheaper tiers' deviation on THIS pool
-REFINE_MIN_SAMPLE = 64      # ... and never fewer than this (calibration and audit alike; 16 until r06: on a 300-image pool the 18 calibration rows understated the
-                            # log-odds bound of the compensated screen -- tighter than any bound before it -- and one pair of a board came back transposed)
+REFINE_MIN_SAMPLE = 64      # ... and never fewer than this (calibration and audit alike; pools under 256 rows: a quarter of the pool, at least 16).  Was 16 until r06: the
+                            # log-odds bound of the compensated screen is tighter than any bound before it, and 18 rows are a thin sample to take a maximum over
 REFINE_SAFETY = 2.0         # bound = safety x the largest deviation seen on any row re-encoded so far (it only ever grows)
 REFINE_SAFETY_MID = 4.0     # the same for the middle tier: its bound rests on a quarter of the calibration rows (an f32 row costs 2.5 split-f16 ones), so it is
                             # given twice the margin instead (8 x was measured: 293 instead of 222 f32 rows per pass on the bench pool, +0.025 s) -- at 1e-5-sized deviations the extra band holds a handful of rows
@@ -312,7 +312,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     cap = _EPS_CAP if form == "relative" else _DELTA_CAP
     audit = audit_rows_default(n) if audit is None else int(audit)
     if audit > 0:
-        audit = min(n, max(REFINE_MIN_SAMPLE, min(audit, n // 16)))       # like the calibration sample: at most 1/16 of the pool, at least REFINE_MIN_SAMPLE rows
+        audit = min(n, max(min(REFINE_MIN_SAMPLE, max(16, n // 4)), min(audit, n // 16)))       # like the calibration sample: at most 1/16 of the pool, at least 64 (16 .. n / 4 on tiny pools)
     level = np.zeros(n, dtype=np.int8)
     dev = [0.0, 0.0]                # largest deviation seen of a level-0 / level-1 value from the better value that replaced it
     n_mid = n_exact = 0
@@ -396,7 +396,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     # calibration rows: `calib`, but at most 1/16 of the pool -- and never fewer than REFINE_MIN_SAMPLE (a bound from a handful of rows is no bound) -- spread evenly over
     # the rows the screen is still trusted on (a row it overflowed on measures nothing; with no such rows: over the pool, as before)
     live = np.flatnonzero(level == 0)
-    want = min(live.size, max(REFINE_MIN_SAMPLE, min(calib, n // 16)))
+    want = min(live.size, max(min(REFINE_MIN_SAMPLE, max(16, n // 4)), min(calib, n // 16)))
     cal = live[np.unique(np.linspace(0, live.size - 1, want).astype(np.int64))] if want else live
     if cal.size == 0:
         pass                            # every row is final already (an all-non-finite screen): nothing to calibrate, nothing left to trust
