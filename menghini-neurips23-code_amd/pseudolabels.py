@@ -80,10 +80,11 @@ def path_ranks(paths):
     return r
 
 
-SCREEN_HILO_ABOVE = 0.04    # bound of the PLAIN-stream screen (log-odds form) above which the compensated stream pays for its +6.6 % encode time (r06 bench pools: the
-                            # near-uniform timed pool, bound 0.025: 0.08 s of re-encodes saved per 50 000 images against 0.115 s of encode; the realistic pool, 0.06:
-                            # the other way round; the stress model, 0.8: 11.3k against 9.0k img/s)
-SCREEN_HILO_GAIN = 2.2      # measured ratio of the two screens' bounds on the same pool (tests/test_gpu_hilo.py)
+# When the compensated screen pays: it costs +6.6 % encode time -- as much as re-encoding 2.2 % of the pool with the split-f16 tier (0.1 ms against 34 us per image) -- and
+# saves the rows its 2.2x tighter bound no longer marks: measured r06 at N = 50 000, 30 % of the plain screen's marked rows on the near-uniform timed pool (2 836 -> 1 999:
+# plain wins by 1 %), 44 % on the structured pool (4 472 -> 2 498: compensated wins by 3 %), and the difference between 9.0k and 11.3k img/s on the stress model.
+SCREEN_HILO_KEEP = 0.040    # a COMPENSATED pass that still marked more than this share of the pool (calibration, audit and non-finite rows aside) keeps the next pass compensated
+SCREEN_HILO_TAKE = 0.064    # a PLAIN pass that marked more than this share sends the next pass to the compensated stream (the same break-even seen from the other side)
 _SCREEN_CHOICE = {}         # pool key -> stream the NEXT pass over it screens with (what its last pass measured)
 
 
@@ -91,10 +92,11 @@ def screen_stream(key=None):
     """Residual stream of the f16 tower when it SCREENS a pool for identical_lists.  "hilo": a compensated pair of f16 numbers per element
     (GRIP_FWD_STREAM_HILO: the 24 roundings of the stream of a ViT-B/16 image no longer accumulate; the embeddings' direction error against the f32
     tower and the measured bound of the screen drop 2.2 - 2.5x, for +6.6 % encode time).  "f16": the plain stream (rounds 1-5).  $GRIP_SCREEN_STREAM =
-    "auto" (default) picks per pool: the first pass over a pool screens compensated (the safe side: it never costs more than 6.6 %), every pass records its
-    bound (note_screen_bound), and the next pass over the same pool -- GRIP re-labels one pool every iteration, pseudo_iterative.py:62-125 -- screens plain
-    where the plain screen's bound stays below SCREEN_HILO_ABOVE.  The lists do not depend on the choice (both screens are certified against the same
-    exact values); only the number of re-encoded rows does.  Train-mode forwards, evaluation and the f16 MODE always keep the plain stream."""
+    "auto" (default) picks per pool: the first pass over a pool screens compensated (the safe side: it never costs more than 6.6 %), every pass records the
+    share of the pool its scan marked (note_screen_bound), and the next pass over the same pool -- GRIP re-labels one pool every iteration,
+    pseudo_iterative.py:62-125 -- screens plain where that share says the tighter bound does not pay (SCREEN_HILO_KEEP / _TAKE).  The lists do not depend on
+    the choice (both screens are certified against the same exact values); only the number of re-encoded rows does.  Train-mode forwards, evaluation and
+    the f16 MODE always keep the plain stream."""
     v = os.environ.get("GRIP_SCREEN_STREAM", "auto")
     if v not in ("auto", "hilo", "f16"):
         raise ValueError(f"GRIP_SCREEN_STREAM={v!r}: expected 'auto', 'hilo' or 'f16'")
@@ -102,13 +104,14 @@ def screen_stream(key=None):
 
 
 def note_screen_bound(key, stream, stats):
-    """Record what a pass measured, for screen_stream("auto"): the plain screen's bound (a compensated pass's bound x SCREEN_HILO_GAIN) decides the next
-    pass's stream.  The statistics are identical on every rank, so every rank decides alike."""
-    if key is None or not stats or stats.get("bound_form") != "odds" or stats.get("rows", 0) == 0:
+    """Record what a pass measured, for screen_stream("auto"): the share of the pool its scan marked decides the next pass's stream.  The statistics are
+    identical on every rank, so every rank decides alike."""
+    if key is None or not stats or stats.get("rows", 0) == 0:
         return
-    plain = stats["eps"] * (SCREEN_HILO_GAIN if stream == "hilo" else 1.0)
-    _SCREEN_CHOICE[key] = "hilo" if (plain > SCREEN_HILO_ABOVE or stats.get("nonfinite_screen_rows", 0)) else "f16"
+    marked = max(0, stats["rows_refined"] - stats["calibration_rows"] - stats["audit_rows"] - stats.get("nonfinite_screen_rows", 0)) / stats["rows"]
+    _SCREEN_CHOICE[key] = "hilo" if marked > (SCREEN_HILO_KEEP if stream == "hilo" else SCREEN_HILO_TAKE) else "f16"
     stats["screen_stream"] = stream
+    stats["screen_marked_share"] = marked
     stats["screen_stream_next_pass"] = _SCREEN_CHOICE[key]
 
 

@@ -64,12 +64,14 @@ def test_persistent_gemm_epilogue_forms_agree(tmp_path):
         "x = torch.randn(704, 3, 224, 224, device='cuda', generator=g)\n"
         "with torch.no_grad(): e = m.encode_image(x)\n"
         "torch.save(e.float().cpu(), sys.argv[1])\n" % repo)
-    out = {}
-    for mode in ("0", "1", "2", "4", "121", "421"):
+    out, procs = {}, {}
+    for mode in ("0", "1", "2", "4", "121", "421"):      # (the six processes share the GPU: most of a run is interpreter + model start-up)
         f = tmp_path / f"emb_{mode}.pt"
         env = dict(os.environ, GRIP_GEMM_EMODE=mode)
-        r = subprocess.run([sys.executable, "-c", script, str(f)], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
+        procs[mode] = (subprocess.Popen([sys.executable, "-c", script, str(f)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), f)
+    for mode, (pr, f) in procs.items():
+        _, err = pr.communicate(timeout=600)
+        assert pr.returncode == 0, err[-2000:]
         out[mode] = torch.load(f)
     ref = out["0"]
     assert torch.isfinite(ref).all() and ref.abs().max() > 0

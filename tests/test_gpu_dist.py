@@ -201,7 +201,7 @@ def test_bench_strong_scaling_mode_and_native_comm_single_rank(tmp_path):
     env = _env(tmp_path)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                          "--pool", "1320", "--strong", "--chunk", "220"], env=env, capture_output=True, text=True, timeout=1200, cwd=tmp_path)
+                          "--pool", "1320", "--strong", "--chunk", "220", "--no-exact", "--no-secondary"], env=env, capture_output=True, text=True, timeout=1200, cwd=tmp_path)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["pool_images_per_gpu"] == 660 and d["config"]["pool_images_total"] == 1320

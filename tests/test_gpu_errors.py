@@ -111,7 +111,7 @@ def test_bad_arguments_are_rejected(model):
     p, n = t._aligned(ws)
     out = torch.empty(2, t.embed_dim, device="cuda")
     with pytest.raises(native.GripError, match="unknown flag bits"):
-        native.check(t.lib.grip_vit_forward(t.handle, x.data_ptr(), 0, None, 0, 2, out.data_ptr(), p, n, 8, None, None))
+        native.check(t.lib.grip_vit_forward(t.handle, x.data_ptr(), 0, None, 0, 2, out.data_ptr(), p, n, 16, None, None))
     with pytest.raises(NotImplementedError):
         from grip_amd.models import CustomImageEncoder
         CustomImageEncoder(model.visual)(x, torch.zeros(2, 128, device="cuda"), deep_embds=torch.zeros(1))

@@ -357,29 +357,31 @@ def test_stress_weights_are_well_conditioned_and_keep_gemm_operands_in_f16_range
 
 
 def test_screen_stream_is_picked_per_pool_from_the_last_pass(monkeypatch):
-    """pseudolabels.screen_stream("auto"): the first pass over a pool screens with the compensated stream; a pass whose (plain-equivalent) bound is small
-    sends the next pass over the SAME pool to the plain stream, a large one (or a non-finite screen row) back to the compensated one; explicit settings
-    win; other pools are not affected."""
+    """pseudolabels.screen_stream("auto"): the first pass over a pool screens with the compensated stream; a compensated pass that marked little sends the
+    next pass over the SAME pool to the plain stream, a plain pass that marked a lot back to the compensated one (two thresholds: the same break-even seen
+    from either side); calibration, audit and non-finite rows do not count; explicit settings win; other pools are not affected."""
     import grip_amd  # noqa: F401
     from grip_amd import pseudolabels as pl
     monkeypatch.delenv("GRIP_SCREEN_STREAM", raising=False)
     pl._SCREEN_CHOICE.clear()
     key, other = ("tower", 50000, 102), ("tower", 2000, 10)
     assert pl.screen_stream(key) == "hilo" and pl.screen_stream() == "hilo"
-    st = {"bound_form": "odds", "rows": 50000, "eps": 0.011, "nonfinite_screen_rows": 0}
-    pl.note_screen_bound(key, "hilo", st)                         # 0.011 x 2.2 = 0.024 < 0.04: the plain screen is cheap enough here
-    assert pl.screen_stream(key) == "f16" and st["screen_stream"] == "hilo" and st["screen_stream_next_pass"] == "f16"
+    st = {"rows": 50000, "rows_refined": 3189, "calibration_rows": 256, "audit_rows": 1024, "nonfinite_screen_rows": 0}
+    pl.note_screen_bound(key, "hilo", st)                         # 1 909 marked rows = 3.8 % < 4 %: the plain screen is cheaper here (the timed bench pool)
+    assert pl.screen_stream(key) == "f16" and st["screen_stream"] == "hilo" and st["screen_stream_next_pass"] == "f16" and abs(st["screen_marked_share"] - 0.03818) < 1e-4
     assert pl.screen_stream(other) == "hilo"
-    pl.note_screen_bound(key, "f16", dict(st, eps=0.025))
+    pl.note_screen_bound(key, "f16", dict(st, rows_refined=3989))     # 5.4 % marked by the plain screen: stays plain (below 6.4 %)
     assert pl.screen_stream(key) == "f16"
-    pl.note_screen_bound(key, "f16", dict(st, eps=0.07))          # the prompts moved: the pool became sensitive
+    pl.note_screen_bound(key, "f16", dict(st, rows_refined=5586))     # the structured pool: 8.6 % -> compensated
     assert pl.screen_stream(key) == "hilo"
-    pl.note_screen_bound(key, "hilo", dict(st, eps=0.011, nonfinite_screen_rows=3))
-    assert pl.screen_stream(key) == "hilo"                        # f16 overflows: the plain stream would not help
-    pl.note_screen_bound(key, "hilo", dict(st, bound_form="relative"))      # (not comparable: left alone)
+    pl.note_screen_bound(key, "hilo", dict(st, rows_refined=3671))    # ... where 4.8 % stay marked: keeps it
     assert pl.screen_stream(key) == "hilo"
-    monkeypatch.setenv("GRIP_SCREEN_STREAM", "f16")
-    assert pl.screen_stream(key) == "f16" and pl.screen_stream(other) == "f16"
+    pl.note_screen_bound(key, "hilo", dict(st, rows_refined=11500, nonfinite_screen_rows=9900))      # overflowed rows are re-encoded either way: 0.6 % marked
+    assert pl.screen_stream(key) == "f16"
+    pl.note_screen_bound(key, "hilo", {"rows": 0})                    # (an empty pool leaves the choice alone)
+    assert pl.screen_stream(key) == "f16"
+    monkeypatch.setenv("GRIP_SCREEN_STREAM", "hilo")
+    assert pl.screen_stream(key) == "hilo" and pl.screen_stream(other) == "hilo"
     monkeypatch.setenv("GRIP_SCREEN_STREAM", "bogus")
     import pytest
     with pytest.raises(ValueError):

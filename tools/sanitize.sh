@@ -3,10 +3,10 @@
 # vocabulary file, per-word cache shared by threads).  CPU only -- GPU AddressSanitizer is not available on this pool; the device code is covered by
 # the parity tests.  1. `make sanitize`: g++ -fsanitize=thread and -fsanitize=address,undefined builds + tests/native/sanitize_driver.cpp under both.
 # 2. the Python tests of the same code (tests/test_refine_scan.py incl. the threaded pre-filter cases, tests/test_tokenizer.py) against the
-# ASan + UBSan library (GRIP_HOST_LIB swaps the host-only symbols; libasan preloaded into the interpreter).  Log: profiles/r05_sanitize.txt.
+# ASan + UBSan library (GRIP_HOST_LIB swaps the host-only symbols; libasan preloaded into the interpreter).  Log: profiles/r06_sanitize.txt (r05: profiles/r05_sanitize.txt).
 set -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$R/profiles/r05_sanitize.txt}
+LOG=${1:-$R/profiles/r06_sanitize.txt}
 {
   echo "## $(date -u +%F) $(g++ --version | head -1)"
   echo "## make -C menghini-neurips23-code_amd/csrc sanitize"
