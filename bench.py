@@ -46,7 +46,7 @@ PEAK_F16_TFLOPS = 2500.0 # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3  # dense f32 MFMA peak (v_mfma_f32_16x16x4_f32), the exact mode's roof
 EPI_NAMES = ["EPI_F32", "EPI_BIAS_F16", "EPI_BIAS_GELU_F16", "EPI_BIAS_RESID", "EPI_F16", "EPI_GELUGRAD_F16", "EPI_F32_SCALE", "EPI_LNFOLD_F16",
              "EPI_LNFOLD_GELU_F16", "EPI_BIAS_RESID_STATS"]
-TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_traffic.json")
 PEAK_CLOCK_MHZ = 2400.0  # the shader clock behind the 2.5 PFLOP/s figure
 
 
