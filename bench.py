@@ -517,7 +517,7 @@ def refine_summary(rs):
     return {"rows_reencoded": rs["rows_refined"], "rows_reencoded_split_f16": rs["rows_mid"], "rows_reencoded_exactly": rs["rows_exact"], "tiers": rs["tiers"],
             "of_rows": rs["rows"], "fraction": rs["rows_refined"] / max(rs["rows"], 1), "nonfinite_screen_rows": rs.get("nonfinite_screen_rows", 0),
             "calibration_rows": rs["calibration_rows"], "rounds": rs["rounds"], "scans": rs["scans"], "rows_per_round": rs["refined_per_round"],
-            "tier_calls": rs["tier_calls"], "screen_stream": rs.get("screen_stream"), "screen_stream_next_pass": rs.get("screen_stream_next_pass"),
+            "tier_calls": rs["tier_calls"], "screen_stream": rs.get("screen_stream"), "screen_stream_next_pass": rs.get("screen_stream_next_pass"), "screen_marked_share": rs.get("screen_marked_share"),
             "bound_form": rs["bound_form"], "bound": rs["eps"], "largest_deviation_seen": rs["max_deviation"], "bound_split_f16": rs["eps_mid"],
             "largest_deviation_seen_split_f16": rs["max_deviation_mid"], "safety": rs["safety"], "safety_split_f16": rs.get("safety_mid"),
             "audit_rows": rs["audit_rows"], "audit_board_rows": rs["audit_board_rows"], "audit_max_deviation": rs["audit_max_deviation"],
@@ -584,7 +584,7 @@ def peaked_pool_block(loop, kind):
     """The index guarantee OFF the degenerate statistics of the timed pool, at the bench size, outside the timed region.  Both
     kinds run the structured pool against class PROTOTYPES as text features, which gives peaked rows with contested arg-maxes:
       "realistic"  the standard synthetic model; text feature of class c = the unit vector along m + 2 (e_c - m), e_c an anchor image's embedding and
-                   m the pool's mean direction: un-centred (it keeps a common component of ~0.8, as CLIP text features do), mean top-1 probability
+                   m the pool's mean direction: un-centred (cosine 0.68 with the mean direction, as CLIP text features keep a common component), mean top-1 probability
                    ~0.6, every class owns arg-maxes, and an f16 direction error of 1e-3 is a logit error of a few 1e-3 -- the regime of a trained
                    CLIP at logit scale 100 far more than the timed pool's near-uniform softmax is;
       "stress"     `clip.load(..., synthetic="stress")` -- outlier channels (|x| ~ 200) in the vision residual stream and an f16 overflow on about a
