@@ -5,7 +5,6 @@ the f16 stream's roundings are most of the f16 tower's deviation); (b) a row doe
 (the persistent 256 x 256 GEMMs of a pool-sized launch and the small-M kernels of a 40-image one must agree bit for bit), with and without a visual
 prompt; (c) the plain stream is untouched (no flag: the embeddings of rounds 1-5).  The reference decides on fp32 values
 (utils/clip_pseudolabels.py:38-41); the screen only has to be close to them and honest about how close (pseudolabels.refine_scan measures it)."""
-import numpy as np
 import pytest
 import torch
 

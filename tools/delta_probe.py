@@ -24,7 +24,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench  # noqa: E402
 import grip_amd  # noqa: E402,F401
-from grip_amd import clip, engine, weights as W, config  # noqa: E402
+from grip_amd import weights as W, config  # noqa: E402
 from grip_amd.clip.clip import load_openai_state_dict  # noqa: E402
 from grip_amd.clip.model import CLIP  # noqa: E402
 
@@ -56,13 +56,7 @@ def unit(e):
     return e / e.norm(dim=-1, keepdim=True)
 
 
-def on_grid(sd):
-    """The state dict with every GEMM-operand weight rounded to the f16 grid (kept f32)."""
-    out = {}
-    for k, v in sd.items():
-        gemm = v.ndim >= 2 and not k.endswith("positional_embedding") and "token_embedding" not in k
-        out[k] = v.astype(np.float16).astype(np.float32) if gemm else v
-    return out
+on_grid = W.on_f16_grid      # every matrix weight rounded to an f16 number (kept f32): what a published fp16 checkpoint holds
 
 
 def build(sd, precision):
