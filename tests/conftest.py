@@ -73,3 +73,17 @@ def write_report(name, payload):
                 json.dump(payload, f, indent=1, default=str)
         except OSError:
             pass
+
+
+def structured_pool(seed, n, res, device="cuda", block=64):
+    """[n, 3, res, res] images of grip_amd.data.synthetic.structured_images on `device`, generated block by block on a thread pool (the counter RNG is
+    numpy on the host: 6 000 ViT-B/16 images take 20 s on one thread -- the GPU suite spent more time drawing images than encoding them)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+    from grip_amd.data.synthetic import structured_images
+    pool = torch.empty(n, 3, res, res, device=device)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for lo, x in ex.map(lambda lo: (lo, structured_images(seed, lo, min(lo + block, n), res)), range(0, n, block)):
+            pool[lo:lo + x.shape[0]] = x.to(device)
+    return pool

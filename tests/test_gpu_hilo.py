@@ -28,10 +28,10 @@ def _dir_err(e, ref):
 def test_compensated_stream_is_closer_to_the_f32_twin_and_chunk_independent(name, n, res, big, small):
     import grip_amd  # noqa: F401
     from grip_amd import clip, rng
-    from grip_amd.data.synthetic import structured_images
     m, _ = clip.load(name, device="cuda")
     twin = m.exact_twin()
-    x = torch.cat([structured_images(77, lo, min(lo + 96, n), res) for lo in range(0, n, 96)]).cuda()
+    from conftest import structured_pool
+    x = structured_pool(77, n, res)
     prefix = torch.from_numpy(rng.normal(3, rng.stream_id("hilo.prefix"), (4, m.dims.vision_width), 0.0, 0.05)).cuda()
     t16, t32 = m.visual.tower, twin.visual.tower
     for pf in (None, prefix):
@@ -80,11 +80,12 @@ def test_identical_lists_screen_with_the_compensated_stream(monkeypatch):
     at most half the plain stream's on the same pool."""
     import grip_amd  # noqa: F401
     from grip_amd import clip, engine, pseudolabels as pl
-    from grip_amd.data.synthetic import pool_paths, structured_images
+    from grip_amd.data.synthetic import pool_paths
     m, _ = clip.load("ViT-B/16", device="cuda")
     twin = m.exact_twin()
     n, C, k = 1536, 24, 8
-    x = torch.cat([structured_images(5, lo, lo + 96, 224) for lo in range(0, n, 96)]).cuda()
+    from conftest import structured_pool
+    x = structured_pool(5, n, 224)
     tok = clip.tokenize([f"a photo of a thing number {i}" for i in range(C)]).cuda()
     paths, labels = pool_paths(n), list(range(C))
     with torch.no_grad():

@@ -165,11 +165,12 @@ def test_three_tier_identical_lists_equal_the_exact_mode():
     f32 tower sees the calibration / audit rows plus a small remainder."""
     import grip_amd  # noqa: F401
     from grip_amd import clip, engine, pseudolabels as pl
-    from grip_amd.data.synthetic import pool_paths, structured_images
+    from grip_amd.data.synthetic import pool_paths
     m, _ = clip.load("ViT-B/16", device="cuda")
     twin, split = m.exact_twin(), m.split_twin()
     n, C, k = 6000, 40, 8
-    x = torch.cat([structured_images(31, lo, min(lo + 500, n), 224) for lo in range(0, n, 500)]).cuda()
+    from conftest import structured_pool
+    x = structured_pool(31, n, 224)
     tok = clip.tokenize([f"a photo of a kind {i}" for i in range(C)]).cuda()
     paths, labels = pool_paths(n), list(range(C))
     with torch.no_grad():

@@ -29,13 +29,11 @@ def stress_problem(n, n_classes, device, seed=77):
 def _stress_problem(n, n_classes, device, seed):
     import grip_amd  # noqa: F401
     from grip_amd import clip, pseudolabels as pl
-    from grip_amd.data.synthetic import pool_paths, structured_images
+    from grip_amd.data.synthetic import pool_paths
     m, _ = clip.load("ViT-B/16", device=device, synthetic="stress")
     twin = m.exact_twin()
-    pool = torch.empty(n, 3, 224, 224, device=device)
-    for lo in range(0, n, 1024):
-        hi = min(lo + 1024, n)
-        pool[lo:hi] = structured_images(seed, lo, hi, 224).to(device)
+    from conftest import structured_pool
+    pool = structured_pool(seed, n, 224, device)
     with torch.no_grad():
         e32 = torch.empty(n, 512, device=device)
         twin.visual.tower.encode_chunks(pool, e32, 0, n, 440, streams=1)
@@ -100,7 +98,7 @@ def test_stress_model_lists_equal_the_reference_functions():
 
     import grip_amd  # noqa: F401
     from grip_amd import clip, engine, pseudolabels as pl
-    from grip_amd.data.synthetic import pool_paths, structured_images
+    from grip_amd.data.synthetic import pool_paths
     from test_gpu_exact import assert_lists_identical
     fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress_vitb16_lists.npz"))
     o_probs = fx["probs"]
@@ -109,9 +107,8 @@ def test_stress_model_lists_equal_the_reference_functions():
     m, _ = clip.load("ViT-B/16", device=dev, synthetic="stress")
     twin = m.exact_twin()
     seed = int(fx["seed"])
-    pool = torch.empty(n, 3, 224, 224, device=dev)
-    for lo in range(0, n, 512):
-        pool[lo:lo + 512] = structured_images(seed, lo, min(lo + 512, n), 224).to(dev)
+    from conftest import structured_pool
+    pool = structured_pool(seed, n, 224, dev)
     txt = torch.from_numpy(fx["txt"]).to(dev)
     scale = float(fx["logit_scale"])
     paths, labels = pool_paths(n), [100 + i for i in range(C)]
