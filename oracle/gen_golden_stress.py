@@ -54,8 +54,10 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------------------------------ reference-run LISTS (r06)
-def lists(n=2048, n_classes=40, seed=77):
-    """`python oracle/gen_golden_stress.py lists` -> tests/golden/stress_vitb16_lists.npz (~6 min on 8 cores).
+def lists(n=2048, n_classes=40, seed=77, variant="stress"):
+    """`python oracle/gen_golden_stress.py lists` -> tests/golden/stress_vitb16_lists.npz (~6 min on 8 cores);
+    `python oracle/gen_golden_stress.py lists realistic` -> tests/golden/realistic_vitb16_lists.npz: the same with the STANDARD synthetic weights and the
+    un-centred prototype blend unit(m + 2 (e_c - m)) of bench.py's `identical_on_realistic_pool` (peaked rows at ordinary logit errors).
 
     The REFERENCE's own utils/clip_pseudolabels.compute_pseudo_labels (:13-117, imported unmodified from /root/reference) driven over `n` structured
     images on the CPU fp32 oracle with the STRESS weights, for k in {3, 16, 10000000}.  The class side is what tests/test_gpu_stress.py uses: the
@@ -71,7 +73,7 @@ def lists(n=2048, n_classes=40, seed=77):
     from utils import clip_pseudolabels as RP     # REFERENCE, unmodified
     from oracle import leaderboard as LB
     d = gcfg.get_dims("ViT-B/16")
-    om = build(weights.stress_state_dict(d, 0), d)
+    om = build(weights.stress_state_dict(d, 0) if variant == "stress" else weights.init_state_dict(d, 0), d)
     paths = pool_paths(n)
     index = {p: i for i, p in enumerate(paths)}
     t0 = time.time()
@@ -86,7 +88,12 @@ def lists(n=2048, n_classes=40, seed=77):
     g = torch.Generator().manual_seed(seed)
     anchors = torch.randperm(n, generator=g)[:n_classes]
     en = emb / emb.norm(dim=-1, keepdim=True)
-    txt = (en[anchors] - en.mean(0, keepdim=True) + 0.003 * torch.randn(n_classes, d.embed_dim, generator=g)).contiguous()
+    mean = en.mean(0, keepdim=True)
+    if variant == "stress":
+        txt = (en[anchors] - mean + 0.003 * torch.randn(n_classes, d.embed_dim, generator=g)).contiguous()
+    else:
+        txt = mean + 2.0 * (en[anchors] - mean)
+        txt = (txt / txt.norm(dim=-1, keepdim=True)).contiguous()
 
     class _FakeImg:
         def __init__(self, idx):
@@ -140,10 +147,13 @@ def lists(n=2048, n_classes=40, seed=77):
     out["probs"] = probs
     print(f"mean top-1 probability {probs.max(1).mean():.3f}, {len(np.unique(pred))} arg-max classes, logit spread "
           f"{np.mean(np.log(np.maximum(probs, 1e-45)).max(1) - np.median(np.log(np.maximum(probs, 1e-45)), 1)):.1f}")
-    path = os.path.join(REPO, "tests", "golden", "stress_vitb16_lists.npz")
+    path = os.path.join(REPO, "tests", "golden", f"{variant}_vitb16_lists.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, f"{time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
-    lists() if len(sys.argv) > 1 and sys.argv[1] == "lists" else main()
+    if len(sys.argv) > 1 and sys.argv[1] == "lists":
+        lists(variant=sys.argv[2] if len(sys.argv) > 2 else "stress")
+    else:
+        main()
