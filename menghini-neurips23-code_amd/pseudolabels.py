@@ -295,7 +295,7 @@ def refine_scan(probs, pred, ranks, k, exact_rows, calib=REFINE_CALIB_ROWS, safe
     probabilities PROVIDED every non-final row obeys its bound.
 
     That proviso is a measured bound, not a theorem about f16 arithmetic, so it is AUDITED: after certification `audit` (default
-    256, $GRIP_REFINE_AUDIT; 0 = off; at most 1/16 of the pool) rows still at level 0 -- half of them members of the final boards where there are any, the rest
+    256, 1 024 for pools of 50 000 rows and more; $GRIP_REFINE_AUDIT; 0 = off; at most 1/16 of the pool but at least 64) rows still at level 0 -- half of them members of the final boards where there are any, the rest
     drawn uniformly from the pool (seeded: every rank draws the same rows) -- are re-encoded by the next tier; if one of them turns
     out to deviate by MORE than the bound it was trusted to, the bound was understated: it is widened to safety x that deviation, the scan
     repeats under it and is audited again (at most REFINE_MAX_AUDITS times, after which every row left is re-encoded).  stats reports the audit (`audit_rows`, `audit_max_deviation`, `audit_widened`), the rows the final lists
