@@ -135,3 +135,56 @@ def test_bounded_scan_runs_on_rank_0_and_is_broadcast(placement):
     (ok0, calls0, scans0, env0), (ok1, calls1, scans1, env1) = ret[0], ret[1]
     assert ok0 and ok1 and scans0 == scans1 >= 2 and env0 is None and env1 is None
     assert calls0 == scans0 and calls1 == (0 if placement == "root" else scans1)
+
+
+def _failing_scan_worker(rank, ws, port, trace, ret):
+    import sys
+    sys.path.insert(0, REPO)
+    import numpy as np
+    import grip_amd  # noqa: F401
+    from grip_amd import dist as gdist, engine, pseudolabels as pl
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(ws),
+                      GRIP_SCAN_PLACEMENT="root", GRIP_COMM_TRACE=trace)
+    gdist.init_from_env(backend="gloo")
+    r = np.random.RandomState(3)
+    n, c = 500, 6
+    p = r.dirichlet(np.ones(c), size=n).astype(np.float32)
+    a = p.argmax(1).astype(np.int32)
+    ranks = pl.path_ranks([f"p/{i:05d}.jpg" for i in range(n)])
+    rel = np.full(n, 1e-2, np.float32)
+    img, cls, amb = pl.scan_bounded(p, a, ranks, rel, 4, 1e-30, "odds")            # a healthy scan first: one broadcast on both ranks
+    healthy = len(img) > 0 and amb.dtype == bool
+    if rank == 0:
+        def boom(*args, **kw):
+            raise engine.native.GripError("bounded leaderboard: out of memory (injected)")
+        engine.leaderboard_scan_bounded = boom
+    try:
+        pl.scan_bounded(p, a, ranks, rel, 4, 1e-30, "odds")
+        raised = None
+    except engine.native.GripError as e:
+        raised = str(e)
+    gdist.barrier()                                                                  # (nobody is left waiting inside the broadcast)
+    ret[rank] = (healthy, raised)
+    dist.destroy_process_group()
+
+
+def test_a_failing_root_scan_raises_on_every_rank_instead_of_hanging(tmp_path):
+    """with the scan placed on rank 0, a failure there used to leave the other ranks inside the broadcast until the collective's watchdog fired.
+    The broadcast now starts with a status word: rank 0 re-raises its own error, every other rank raises a GripError that points at rank 0 -- and
+    $GRIP_COMM_TRACE shows the two broadcasts (the healthy scan's and the failed one's) on both ranks."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    trace = str(tmp_path / "comm.log")
+    procs = [ctx.Process(target=_failing_scan_worker, args=(r, 2, port, trace, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] is not None and "injected" in ret[0][1]
+    assert ret[1][1] is not None and "rank 0" in ret[1][1]
+    lines = open(trace).read().splitlines()
+    for r in (0, 1):
+        assert sum(l.startswith(f"rank{r} broadcast ") for l in lines) == 2, lines
