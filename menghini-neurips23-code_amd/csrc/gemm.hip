@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(512) void gemm_ringw_kernel(GemmArgs g, int tiles_m
             if (lane == 0) g.coop_counter[bid * 4 + wave] = 0;            // ready for the next launch (stream order: nobody else touches it now)
         }
     }
-    epilogue_rows<EPI, WMF, 2, FOLD>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane, pre, FOLD ? cb : nullptr);
+    epilogue_rows<EPI, WMF, (WMF & 1) ? 1 : 2, FOLD>(g, acc, (float*)lds2 + wave * EPI_SLAB_FLOATS, m0 + wr * WMF * 16, n0 + wc * 64, lane, pre, FOLD ? cb : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2170,6 +2170,34 @@ static int launch_ringw(int epi, const GemmArgs& a, dim3 grid, hipStream_t s) {
     return GRIP_OK;
 }
 
+// The 96-row form of the loader-wave ring (WMF = 3; r06): residual epilogues only (the LayerNorm-folded ones fetch their row statistics with a power-of-two
+// lane map).  For the K = 4 d residual GEMM of an image-tower prompt step -- M = 3 408, N = 768: 27 x 6 = 162 tiles of 128 rows leave 94 CUs idle for the whole
+// 48-slice walk; 36 x 6 = 216 tiles of 96 rows put 84 % of the chip on a walk that is a quarter shorter per tile.
+static int launch_ringw96(int epi, const GemmArgs& a, hipStream_t s) {
+    constexpr int NST = 5, WMF = 3, BMT = 96;
+    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = a.N / BN;
+    constexpr size_t lds = (size_t)NST * (BMT + BN) * BK * 2;
+    GRIP_REQUIRE((int64_t)tiles_m * BMT <= a.m_pad && a.K / BK >= NST - 1 && a.ksplit <= 1, "gemm_ringw96: shape (M=%d K=%d m_pad=%lld ksplit=%d)", a.M, a.K, (long long)a.m_pad, a.ksplit);
+    dim3 grid(tiles_m * tiles_n);
+#define GRIP_GEMM_CASE(E)                                                                                                   \
+    case E: {                                                                                                               \
+        static bool configured = false;                                                                                     \
+        if (!configured) {                                                                                                  \
+            GRIP_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_ringw_kernel<E, NST, WMF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                              \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((gemm_ringw_kernel<E, NST, WMF>), grid, dim3(512), lds, s, a, tiles_m, tiles_n);                  \
+    } break;
+    switch (epi) {
+        GRIP_GEMM_CASE(EPI_BIAS_RESID)
+        GRIP_GEMM_CASE(EPI_BIAS_RESID_STATS)
+        default: GRIP_REQUIRE(false, "gemm_ringw96: residual epilogues only (epi %d)", epi);
+    }
+#undef GRIP_GEMM_CASE
+    GRIP_CHECK_HIP(hipGetLastError());
+    return GRIP_OK;
+}
+
 static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* chosen) {
     // Row-dependent K rotation (GemmArgs::rot_rows = the caller's permission: train-mode launches only).  In a prompt step every GEMM
     // reads weights nobody has touched since the previous step; with all tile rows of a column panel walking K in lockstep, each of them
@@ -2297,6 +2325,12 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     if (wspec && (int64_t)grid.x * ksplit <= 256) {
         const int nk = a.K / BK / ksplit;
         if (variant == 4 && nk >= 3) return launch_ringw<2, 4>(epi, a, grid, s);
+        if (variant == 1 && nk > 12 && ksplit == 1 && a.variant == 0 && (epi == EPI_BIAS_RESID || epi == EPI_BIAS_RESID_STATS)) {
+            // long walk, residual epilogue, fewer 128-row tiles than CUs: the 96-row form when it fills more of them (and its rows are allocated)
+            static const bool r96 = !(getenv("GRIP_GEMM_R96") && atoi(getenv("GRIP_GEMM_R96")) == 0);     // developer A/B
+            const int64_t t96 = (int64_t)((a.M + 95) / 96) * (a.N / BN);
+            if (r96 && t96 <= 256 && t96 > (int64_t)grid.x && (int64_t)((a.M + 95) / 96) * 96 <= a.m_pad) return launch_ringw96(epi, a, s);
+        }
         if (variant == 1 && nk > 12) return launch_ringw<4, 5>(epi, a, grid, s);
         if (variant == 1 && nk >= 2) return launch_ringw<4, 3>(epi, a, grid, s);
     }

@@ -265,3 +265,33 @@ def test_layernorm_folded_into_gemm(M, d, N2, variant):
     native.check(lib.grip_debug_gemm_ln(8, _p(x), _p(Wg), M, N2, d, _p(bb), None, _p(out), _p(pre), None, _p(rowstat), _p(cs), Mp, variant, _stream()))
     torch.testing.assert_close(pre.float(), want, rtol=4e-3, atol=4e-3)
     torch.testing.assert_close(out.float(), quick_gelu(want), rtol=4e-3, atol=4e-3)
+
+
+def test_the_96_row_loader_wave_tile_is_the_128_row_one_bit_for_bit():
+    """r06: the K = 4 d residual GEMM of an image-tower prompt step (M = 3 408 rows, N = 768, K = 3 072) runs on 96-row tiles of the loader-wave ring
+    (216 workgroups instead of 162 on 256 CUs).  The tile shape changes which workgroup computes a row, never the row: same K order, same
+    statistics tree -- bit-identical to the 128-row launch (debug variant 1) with and without the row statistics, and correct against float64."""
+    native, lib = _lib()
+    M, N, K = 3408, 768, 3072
+    Mp = (M + 255) // 256 * 256
+    g = torch.Generator(device="cuda").manual_seed(96)
+    A = torch.randn(Mp, K, device="cuda", generator=g).half()
+    A[M:] = float("nan")
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g).half()
+    ref = A[:M].double() @ W.double().t() + bias.double() + resid.double()
+    outs, stats = {}, {}
+    for variant in (0, 1):          # 0 = the launcher's choice (the 96-row form for this shape), 1 = 128 x 128 tiles
+        o = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        native.check(lib.grip_debug_gemm(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), None, _p(o), None, 1.0, Mp, variant, _stream()))
+        o2 = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        st = torch.zeros(N // 64, M, 2, device="cuda")
+        native.check(lib.grip_debug_gemm_ln(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), _p(o2), None, _p(st), None, None, Mp, variant, _stream()))
+        assert torch.equal(o, o2)
+        outs[variant], stats[variant] = o, st
+    assert torch.equal(outs[0], outs[1]) and torch.equal(stats[0], stats[1])
+    torch.testing.assert_close(outs[0].double(), ref, rtol=2e-3, atol=2e-3)
+    # the statistics are (sum, sum of squares) of what the epilogue added into the stream, per 64-column tile
+    v = (A[:M].float() @ W.float().t() + bias + resid.float()).reshape(M, N // 64, 64)
+    torch.testing.assert_close(stats[0][..., 0].t(), v.sum(-1), rtol=1e-3, atol=2e-2)
