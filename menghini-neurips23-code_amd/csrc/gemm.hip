@@ -2170,8 +2170,8 @@ static int launch_ringw(int epi, const GemmArgs& a, dim3 grid, hipStream_t s) {
     return GRIP_OK;
 }
 
-// The 96-row form of the loader-wave ring (WMF = 3; r06): residual epilogues only (the LayerNorm-folded ones fetch their row statistics with a power-of-two
-// lane map).  For the K = 4 d residual GEMM of an image-tower prompt step -- M = 3 408, N = 768: 27 x 6 = 162 tiles of 128 rows leave 94 CUs idle for the whole
+// The 96-row form of the loader-wave ring (WMF = 3; r06): residual and plain f16 epilogues only (the LayerNorm-folded ones fetch their row statistics with a
+// power-of-two lane map).  For the K = 4 d residual GEMM of an image-tower prompt step -- M = 3 408, N = 768: 27 x 6 = 162 tiles of 128 rows leave 94 CUs idle for the whole
 // 48-slice walk; 36 x 6 = 216 tiles of 96 rows put 84 % of the chip on a walk that is a quarter shorter per tile.
 static int launch_ringw96(int epi, const GemmArgs& a, hipStream_t s) {
     constexpr int NST = 5, WMF = 3, BMT = 96;
@@ -2191,7 +2191,8 @@ static int launch_ringw96(int epi, const GemmArgs& a, hipStream_t s) {
     switch (epi) {
         GRIP_GEMM_CASE(EPI_BIAS_RESID)
         GRIP_GEMM_CASE(EPI_BIAS_RESID_STATS)
-        default: GRIP_REQUIRE(false, "gemm_ringw96: residual epilogues only (epi %d)", epi);
+        GRIP_GEMM_CASE(EPI_F16)
+        default: GRIP_REQUIRE(false, "gemm_ringw96: residual / plain f16 epilogues only (epi %d)", epi);
     }
 #undef GRIP_GEMM_CASE
     GRIP_CHECK_HIP(hipGetLastError());
@@ -2321,6 +2322,15 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
         GRIP_REQUIRE(wspec, "gemm: cooperative split-K needs the loader-wave kernels (GRIP_GEMM_WSPEC=0 is set)");
         grid.x = (grid.x + 7) / 8 * 8;       // the splits of a tile on one XCD (gemm_ringw_kernel)
         return launch_ringw<2, 4>(epi, a, grid, s);
+    }
+    {   // the 96-row loader-wave tile also for SHORT walks whose 64-row tiles outnumber the CUs (M = 3 408, N = K = 768 -- the out-proj forward of an image-tower
+        // prompt step and its input gradient: 324 tiles of 64 rows at two workgroups per CU against 216 of 96 rows at one: VPT step 2.82 -> 2.78 ms, UPT
+        // 3.15 -> 3.12, profiles/r06_r96_ab.txt).  GRIP_GEMM_R96 (developer A/B): 0 = no 96-row tiles, 1 = long walks only, 2 (default) = both
+        static const int r96mode = getenv("GRIP_GEMM_R96") ? atoi(getenv("GRIP_GEMM_R96")) : 2;
+        const int64_t t96 = (int64_t)((a.M + 95) / 96) * (a.N / BN), t64 = (int64_t)((a.M + 63) / 64) * (a.N / BN);
+        if (r96mode >= 2 && wspec && ksplit == 1 && a.variant == 0 && variant == 4 && (epi == EPI_BIAS_RESID || epi == EPI_BIAS_RESID_STATS || epi == EPI_F16) &&
+            t96 <= 256 && t64 > 256 && (int64_t)((a.M + 95) / 96) * 96 <= a.m_pad && a.K / BK >= 4)
+            return launch_ringw96(epi, a, s);
     }
     if (wspec && (int64_t)grid.x * ksplit <= 256) {
         const int nk = a.K / BK / ksplit;

@@ -267,12 +267,13 @@ def test_layernorm_folded_into_gemm(M, d, N2, variant):
     torch.testing.assert_close(out.float(), quick_gelu(want), rtol=4e-3, atol=4e-3)
 
 
-def test_the_96_row_loader_wave_tile_is_the_128_row_one_bit_for_bit():
+@pytest.mark.parametrize("K", [3072, 768])
+def test_the_96_row_loader_wave_tile_is_the_128_row_one_bit_for_bit(K):
     """r06: the K = 4 d residual GEMM of an image-tower prompt step (M = 3 408 rows, N = 768, K = 3 072) runs on 96-row tiles of the loader-wave ring
     (216 workgroups instead of 162 on 256 CUs).  The tile shape changes which workgroup computes a row, never the row: same K order, same
     statistics tree -- bit-identical to the 128-row launch (debug variant 1) with and without the row statistics, and correct against float64."""
     native, lib = _lib()
-    M, N, K = 3408, 768, 3072
+    M, N = 3408, 768         # K = 3 072: the c_proj forward; K = 768: the out-proj forward and (plain f16 epilogue) its input gradient
     Mp = (M + 255) // 256 * 256
     g = torch.Generator(device="cuda").manual_seed(96)
     A = torch.randn(Mp, K, device="cuda", generator=g).half()
@@ -291,6 +292,13 @@ def test_the_96_row_loader_wave_tile_is_the_128_row_one_bit_for_bit():
         assert torch.equal(o, o2)
         outs[variant], stats[variant] = o, st
     assert torch.equal(outs[0], outs[1]) and torch.equal(stats[0], stats[1])
+    plain = {}
+    for variant in (0, 1):          # EPI_F16 (the dgrad GEMMs of the step)
+        o = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        native.check(lib.grip_debug_gemm(4, _p(A), _p(W), M, N, K, None, None, None, _p(o), None, 1.0, Mp, variant, _stream()))
+        plain[variant] = o
+    assert torch.equal(plain[0], plain[1])
+    torch.testing.assert_close(plain[0].double(), A[:M].double() @ W.double().t(), rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(outs[0].double(), ref, rtol=2e-3, atol=2e-3)
     # the statistics are (sum, sum of squares) of what the epilogue added into the stream, per 64-column tile
     v = (A[:M].float() @ W.float().t() + bias + resid.float()).reshape(M, N // 64, 64)
