@@ -244,7 +244,7 @@ def lookahead_image_features(clip_model, batches, group=8, overlap=None):
     side stream (engine.masked_stream; the persistent kernels size their grids to it, grip_set_cu_budget) BEFORE group g's features are yielded, so that
     it could run beside the prompt steps -- a latency-bound chain of ~176 launches of 28 - 60 workgroups each -- on the CUs the mask leaves free.  Same
     features bit for bit (tests/test_gpu_determinism.py), but no overlap happens on this runtime: encode 28.5 ms + 51 steps 56.3 ms take 102 ms
-    "together" (88 ms with an ordinary side stream), tools/overlap_probe.py; DESIGN 8.6.
+    "together" (88 ms with an ordinary side stream), tools/overlap_probe.py; profiles/HISTORY.md 11.6.
 
     `batches` yields tuples whose first element is the image batch [B, 3, R, R] (any further elements are passed through);
     yields (features [B, embed_dim], *rest) in the same order."""
