@@ -2334,6 +2334,16 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
     }
     if (wspec && (int64_t)grid.x * ksplit <= 256) {
         const int nk = a.K / BK / ksplit;
+        {   // 32-row tiles (WMF = 1; r06) where the 64-row ones fill at most half the chip -- the text tower's M = 425 GEMMs of a CoOp step: 28 - 112 tiles of 64 rows
+            // become 56 - 224 of 32 rows, each staging 160 instead of 192 rows per K slice through its CU's LDS-DMA path: graphed CoOp step 1.11 - 1.16 -> 1.076 ms
+            // (profiles/r06_r32_ab.txt).  Same products in the same order: bit-identical (tests/test_gpu_kernels.py).  GRIP_GEMM_R32=0: developer A/B
+            static const bool r32 = !(getenv("GRIP_GEMM_R32") && atoi(getenv("GRIP_GEMM_R32")) == 0);
+            const int64_t t32 = (int64_t)((a.M + 31) / 32) * (a.N / BN);
+            if (r32 && variant == 4 && nk >= 3 && !coop && ksplit == 1 && a.variant == 0 && (int64_t)grid.x <= 128 && t32 <= 256) {
+                dim3 g32((unsigned)t32, 1);
+                return launch_ringw<1, 4>(epi, a, g32, s);
+            }
+        }
         if (variant == 4 && nk >= 3) return launch_ringw<2, 4>(epi, a, grid, s);
         if (variant == 1 && nk > 12 && ksplit == 1 && a.variant == 0 && (epi == EPI_BIAS_RESID || epi == EPI_BIAS_RESID_STATS)) {
             // long walk, residual epilogue, fewer 128-row tiles than CUs: the 96-row form when it fills more of them (and its rows are allocated)

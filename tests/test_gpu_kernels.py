@@ -303,3 +303,45 @@ def test_the_96_row_loader_wave_tile_is_the_128_row_one_bit_for_bit(K):
     # the statistics are (sum, sum of squares) of what the epilogue added into the stream, per 64-column tile
     v = (A[:M].float() @ W.float().t() + bias + resid.float()).reshape(M, N // 64, 64)
     torch.testing.assert_close(stats[0][..., 0].t(), v.sum(-1), rtol=1e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(425, 512, 512), (425, 1536, 512), (425, 2048, 512), (201, 512, 2048)])
+def test_the_32_row_loader_wave_tile_is_the_64_row_one_bit_for_bit(M, N, K):
+    """r06: the text tower's GEMMs of a CoOp step (M = 17 + 102 x 4 = 425 rows) run on 32-row tiles of the loader-wave ring where the 64-row tiles fill at
+    most half the chip.  Every epilogue -- f32, bias, bias + QuickGELU, residual (with and without the row statistics), plain f16, GELU-gradient, and the two
+    LayerNorm-folded ones -- must give the bits of the 64-row launch (debug variant 4)."""
+    native, lib = _lib()
+    Mp = (M + 255) // 256 * 256
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = (torch.randn(Mp, K, device="cuda", generator=g) * 2 + 0.3).half()
+    A[M:] = float("nan")
+    W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g).half()
+    aux = torch.randn(M, N, device="cuda", generator=g).half()
+    colsum = W.float().sum(1).contiguous()
+    rowstat = torch.stack([A[:M].float().mean(1), torch.rsqrt(A[:M].float().var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    got = {}
+    for variant in (0, 4):
+        outs = []
+        o32 = torch.zeros(M, N, device="cuda")
+        native.check(lib.grip_debug_gemm(0, _p(A), _p(W), M, N, K, None, None, None, _p(o32), None, 1.0, Mp, variant, _stream()))
+        outs.append(o32)
+        for epi, b, r, x in ((1, bias, None, None), (2, bias, None, None), (3, bias, resid, None), (4, None, None, None), (5, None, None, aux)):
+            o = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+            pre = torch.zeros(M, N, device="cuda", dtype=torch.float16) if epi == 2 else None
+            native.check(lib.grip_debug_gemm(epi, _p(A), _p(W), M, N, K, _p(b), _p(r), _p(x), _p(o), _p(pre), 1.0, Mp, variant, _stream()))
+            outs += [o] + ([pre] if pre is not None else [])
+        st = torch.zeros(N // 64, M, 2, device="cuda")
+        o = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        native.check(lib.grip_debug_gemm_ln(3, _p(A), _p(W), M, N, K, _p(bias), _p(resid), _p(o), None, _p(st), None, None, Mp, variant, _stream()))
+        outs += [o, st]
+        for epi in (7, 8):
+            o = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+            pre = torch.zeros(M, N, device="cuda", dtype=torch.float16) if epi == 8 else None
+            native.check(lib.grip_debug_gemm_ln(epi, _p(A), _p(W), M, N, K, _p(bias), None, _p(o), _p(pre), None, _p(rowstat), _p(colsum), Mp, variant, _stream()))
+            outs += [o] + ([pre] if pre is not None else [])
+        got[variant] = outs
+    for a, b in zip(got[0], got[4]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(got[0][0], A[:M].float() @ W.float().t(), rtol=1e-4, atol=1e-3)
