@@ -2094,10 +2094,15 @@ int gemm_pick_ksplit(int M, int N, int K) {
         }
     }
     int best = 1;
+    const int64_t t32 = (int64_t)((M + 31) / 32) * (N / BN);
     for (int f : {2, 3, 4, 6, 8}) {
         if (nk % f || nk / f < 3) continue;
         best = f;                                   // a few dozen tiles (the shared-prefix text rows): as many K slices as keep 3 k-steps each
-        if (nk / f >= 4 && tiles * f >= 256) break; // the smallest factor that reaches every CU
+        // workgroups of the launch: the launcher runs small launches on 32-row tiles (r06, launch_gemm_impl), which doubles them -- so half the splits already
+        // reach (nearly) every CU: M = 425, N = 512, K = 1 536 / 2 048: 4 splits x 56 tiles = 224 workgroups walking 6 - 8 slices instead of 8 x 28 walking 3 - 4,
+        // and ln_bwd_add sums 4 partials instead of 8 (graphed CoOp step 1.075 -> 1.041 ms, profiles/r06_ksplit_ab.txt)
+        const int64_t wgs = (tiles * f <= 128 && t32 * f <= 256) ? t32 * f : tiles * f;
+        if (nk / f >= 4 && wgs >= 224) break;       // the smallest factor that reaches (7/8 of) every CU
     }
     return best;
 }
@@ -2339,8 +2344,9 @@ static int launch_gemm_impl(int epi, const GemmArgs& a_in, hipStream_t s, int* c
             // (profiles/r06_r32_ab.txt).  Same products in the same order: bit-identical (tests/test_gpu_kernels.py).  GRIP_GEMM_R32=0: developer A/B
             static const bool r32 = !(getenv("GRIP_GEMM_R32") && atoi(getenv("GRIP_GEMM_R32")) == 0);
             const int64_t t32 = (int64_t)((a.M + 31) / 32) * (a.N / BN);
-            if (r32 && variant == 4 && nk >= 3 && !coop && ksplit == 1 && a.variant == 0 && (int64_t)grid.x <= 128 && t32 <= 256) {
-                dim3 g32((unsigned)t32, 1);
+            // (split-K input-gradient GEMMs too -- EPI_F32 partials, one grid row per split -- as long as all splits of the 32-row tiles still fit one per CU)
+            if (r32 && variant == 4 && nk >= 3 && !coop && (ksplit == 1 || epi == EPI_F32) && a.variant == 0 && (int64_t)grid.x * ksplit <= 128 && t32 * ksplit <= 256) {
+                dim3 g32((unsigned)t32, (unsigned)ksplit);
                 return launch_ringw<1, 4>(epi, a, g32, s);
             }
         }
