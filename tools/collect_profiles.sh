@@ -11,6 +11,9 @@ if [ "${SKIP_STATS:-0}" != "1" ]; then
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o r -- python $R/bench.py --no-cpu-baseline --no-secondary --no-exact > $OUT/bench_line.json 2> $OUT/bench_stderr.log
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 fi
+# (the PMC passes time ONE pass over a fresh pool, which the auto policy screens with the compensated stream; the timed passes of the default bench screen the
+# noise pool with the plain stream -- so the counters are collected with the plain stream unless the caller says otherwise: r06)
+export GRIP_SCREEN_STREAM=${GRIP_SCREEN_STREAM:-f16}
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
   N=$(echo $C | cut -d' ' -f1)
   # (--lookahead 1: the prompt steps encode their own 16 images, so every persistent-GEMM launch in the pass is a full pool chunk and the
@@ -33,5 +36,6 @@ with open(dst, "w", newline="") as f:
         w.writerow([k, c, n, s, s / n])
 PY
 done
+unset GRIP_SCREEN_STREAM
 if [ "${FULL_LINE:-1}" = "1" ]; then timeout 900 python $R/bench.py > $OUT/bench_line_full.json 2>> $OUT/bench_stderr.log; fi
 ls -la $OUT
