@@ -22,7 +22,7 @@
 // address and on the ds_read_b128 address: conflict-free).  A lane's MFMA fragment (8 consecutive k of one row) is chunk
 // (lane >> 4) of the row's hi half and chunk 4 + (lane >> 4) of its lo half: one ds_read_b128 each.
 //
-// Kernels: default = 256 x 256 tile, 8 waves as 2 x 4 (128 x 64 per wave), two 64-KiB stages (see `gemm_split1_kernel`); scaled variant =
+// Kernels: default = 256 x 256 tile, 8 waves as 4 x 2 (64 x 128 per wave), two 64-KiB stages (see `gemm_split1_kernel`); scaled variant =
 // 256 x 128 tile, 8 waves as 4 x 2, K staged 32 wide in a 3-slot ring of 48 KiB stages with counted vmcnt.  Operands are swapped
 // (W fragment first) so a lane ends with four consecutive output columns of one row.
 #include <math.h>
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g, int tile
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // Single-accumulator form (the default): with the lo parts UNSCALED (lo = f16(x - hi); gfx950's f16 MFMA takes subnormal inputs unflushed,
 // tools/micro/mfma_denorm.hip) all three products have the same scale and add into ONE accumulator, so the kernel affords the 256 x 256 tile
-// of the f16 kernels (8 waves as 2 x 4, 128 x 64 per wave = 8 x 4 fragments, 128 accumulator registers): per K step of 32 a wave issues 24
+// of the f16 kernels (8 waves, 32 fragment pairs per wave, 128 accumulator registers): per K step of 32 a wave issues 24
 // fragment reads for 96 MFMAs and the workgroup stages 64 KiB for 768 MFMAs -- a third less LDS traffic and DMA feed per MFMA than the
 // 256 x 128 two-accumulator form, which measured 290 - 330 TFLOP/s f32-equivalent (0.39 of the f16 MFMA peak; an LDS / feed limit: pipelining
 // its fragment reads through registers changed nothing).  Weights are stored scaled by 2^8 (exact) so that the lo part of a typical |w| ~ 0.02
@@ -266,8 +266,13 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs g, int tile
 // published CLIP checkpoint are (fp16 archives; the reference's CPU path is clip.load(..., "cpu") = those values cast up, models/clip_encoders.py:
 // 108-119) -- so the a_hi w_lo product is dropped: two MFMA passes instead of three per fragment pair, the W lo fragments are never read.
 // grip_tower_finalize sets the flag when the split of the weights left no non-zero lo part.
+// Wave layout (r06): the 8 waves as 4 x 2 (64 rows x 128 columns per wave = 4 x 8 fragments), not the f16 kernels' 2 x 4 (128 x 64).  Only the A side needs both
+// of its halves in the two-pass form, so the A side is the short one: 4 a_hi + 4 a_lo + 8 w_hi = 16 fragment reads per K step and wave instead of 20 (three-pass:
+// 24 either way).  An output element's sum does not depend on the wave that forms it (same K order, same pass order): bit-identical to the 2 x 4 layout, whole
+// split tower 10.6k -> 10.95k img/s on fp16-checkpoint weights, 9.35k -> 9.53k otherwise (profiles/r06_split_wave_layout_ab.txt).
 template <int EPI, bool WLO>
 __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int FI = 4, FJ = 8;          // A / W fragments (16 rows each) per wave
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave >> 1, wc = wave & 1;
 
     // staging: wave w fills rows [w*32, +32) of the A tile and of the W tile (4 + 4 pieces of 8 rows x 128 B)
     const int srow = lane >> 3;
@@ -292,14 +297,14 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
 
     const int frow = lane & 15, fgrp = lane >> 4;
     const int swz_hi = (fgrp ^ (lane & 7)) * 16, swz_lo = ((4 + fgrp) ^ (lane & 7)) * 16;
-    const int a_row = (wr * 128 + frow) * SPL_ROWB;
-    const int b_row = SP1_BM * SPL_ROWB + (wc * 64 + frow) * SPL_ROWB;
+    const int a_row = (wr * FI * 16 + frow) * SPL_ROWB;
+    const int b_row = SP1_BM * SPL_ROWB + (wc * FJ * 16 + frow) * SPL_ROWB;
 
-    f32x4 acc[8][4];
+    f32x4 acc[FI][FJ];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / 32;
     int ks_stage = (int)(((int64_t)tn * nk) / tiles_n);       // K rotation per column panel (see the two-accumulator kernel / gemm.hip)
@@ -320,15 +325,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage kt
         __builtin_amdgcn_s_barrier();                         // stage kt visible; the other slot fully read
         const char* st = lds + (kt & 1) * SP1_STAGE_B;
-        half8 ah[8], al[8], wh[4], wl[4];
-        // The hi fragments (12 reads) go out first; the 12 lo reads follow BETWEEN the first 24 MFMAs, which only need hi operands.  (All 24 up
-        // front would exceed the 4-bit lgkmcnt: the compiler then waits for every read before the first product -- 192 ds_read_b128 per
-        // workgroup and K step in front of idle matrix pipes.)
+        half8 ah[FI], al[FI], wh[FJ], wl[FJ];
+        // The hi fragments (12 reads) go out first; the lo reads (12, two-pass: the A side's 8 / 4) follow BETWEEN the first 24 MFMAs, which only need
+        // hi operands.  (All 24 up front would exceed the 4-bit lgkmcnt: the compiler then waits for every read before the first product -- 192
+        // ds_read_b128 per workgroup and K step in front of idle matrix pipes.)
         wh[0] = *(const half8*)(st + b_row + swz_hi);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ah[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_hi);
+        for (int i = 0; i < FI; ++i) ah[i] = *(const half8*)(st + a_row + i * 16 * SPL_ROWB + swz_hi);
 #pragma unroll
-        for (int j = 1; j < 4; ++j) wh[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_hi);
+        for (int j = 1; j < FJ; ++j) wh[j] = *(const half8*)(st + b_row + j * 16 * SPL_ROWB + swz_hi);
         __builtin_amdgcn_sched_barrier(0);
         // stage kt + 1 into the other slot, one piece after every twelfth (WLO: eighth) MFMA (past the end: a valid slice into a slot nobody reads)
         char* abase = lds + ((kt + 1) & 1) * SP1_STAGE_B + wave * 32 * SPL_ROWB;
@@ -336,17 +341,17 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
         const char* as = a_src + (size_t)ks_stage * SPL_ROWB;
         const char* ws = w_src + (size_t)ks_stage * SPL_ROWB;
         ks_stage = next_slice(ks_stage);
-        constexpr int NQ = WLO ? 96 : 64, PIECE_EVERY = NQ / 8, LO_READS = WLO ? 12 : 8;
+        constexpr int NQ = WLO ? 96 : 64, PIECE_EVERY = NQ / 8, LO_READS = WLO ? 12 : FI;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {        // passes over the 32 fragment pairs (j-major): w_hi a_hi, [w_lo a_hi,] w_hi a_lo
-            const int pass = q >> 5, j = (q >> 3) & 3, i = q & 7;
+            const int pass = q >> 5, j = ((q & 31) / FI), i = q % FI;
             if (pass == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
             else if (WLO && pass == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
-            if (q < 2 * LO_READS && !(q & 1)) {         // a lo read after every other MFMA of the first pass: [w_lo 0..3, then] a_lo 0..7
-                const int r = (q >> 1) + (WLO ? 0 : 4);
-                if (r < 4) wl[r] = *(const half8*)(st + b_row + r * 16 * SPL_ROWB + swz_lo);
-                else al[r - 4] = *(const half8*)(st + a_row + (r - 4) * 16 * SPL_ROWB + swz_lo);
+            if (q < 2 * LO_READS && !(q & 1)) {         // a lo read after every other MFMA of the first pass: [the w_lo fragments, then] the a_lo fragments
+                const int r = (q >> 1) + (WLO ? 0 : FJ);
+                if (r < FJ) wl[r] = *(const half8*)(st + b_row + r * 16 * SPL_ROWB + swz_lo);
+                else al[r - FJ] = *(const half8*)(st + a_row + (r - FJ) * 16 * SPL_ROWB + swz_lo);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (q % PIECE_EVERY == PIECE_EVERY - 1) {
@@ -361,13 +366,13 @@ __global__ __launch_bounds__(512, 2) void gemm_split1_kernel(GemmArgs g, int til
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (dead) stage must have landed before the workgroup gives its LDS back
 
     constexpr bool HAS_BIAS = (EPI == EPI_BIAS_F16 || EPI == EPI_BIAS_GELU_F16 || EPI == EPI_BIAS_RESID);
-    const int row0 = m0 + wr * 128 + frow, col0 = n0 + wc * 64 + fgrp * 4;
+    const int row0 = m0 + wr * FI * 16 + frow, col0 = n0 + wc * FJ * 16 + fgrp * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < FJ; ++j) {
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
         if constexpr (HAS_BIAS) b = *(const f32x4*)(g.bias + col0 + j * 16);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < FI; ++i) {
             const int row = row0 + i * 16;
             if (row >= g.M) continue;
             const int col = col0 + j * 16;
