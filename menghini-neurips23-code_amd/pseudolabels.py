@@ -550,6 +550,14 @@ def take_images(images, idx):
     return images.take(idx)
 
 
+def balanced_chunk(n_rows, chunk):
+    """Rows per launch when `n_rows` rows go through a tower at most `chunk` at a time: the smallest size that keeps the number of launches
+    (1 024 audit rows at 880 -> 2 x 512, not 880 + 144: the tail launch left the 256 x 256 GEMM tiles of the refinement towers a chip's worth of
+    workgroups short).  Rows do not depend on the chunking."""
+    parts = max(1, -(-int(n_rows) // max(1, int(chunk))))
+    return max(1, -(-int(n_rows) // parts))
+
+
 def tier_rows(tower, fetch, txt, scale, n, lo, hi, chunk, prefix=None, argmax_on="probs", on_rows=None, timer=None):
     """A refinement tier as refine_scan's callback: rows(idx) -> (probs [len(idx), C], arg-max) of the global rows `idx` (ascending) re-encoded by `tower`.
     Each rank encodes the rows of its own shard [lo, hi) -- `fetch(global_rows)` returns their images -- and one padded all-gather assembles the rest.
@@ -566,7 +574,7 @@ def tier_rows(tower, fetch, txt, scale, n, lo, hi, chunk, prefix=None, argmax_on
         with torch.cuda.stream(side):
             local = torch.empty(len(mine), tower.embed_dim, dtype=torch.float32, device=dev)
             if len(mine):
-                tower.encode_chunks(lambda a, b: fetch(mine[a:b]), local, 0, len(mine), chunk, prefix, streams=tier_streams())
+                tower.encode_chunks(lambda a, b: fetch(mine[a:b]), local, 0, len(mine), balanced_chunk(len(mine), chunk), prefix, streams=tier_streams())
             if on_rows is not None:
                 on_rows(len(mine))
             got = gdist.allgather_selected(local, idx, n, tag="refined_rows")

@@ -387,3 +387,17 @@ def test_screen_stream_is_picked_per_pool_from_the_last_pass(monkeypatch):
     with pytest.raises(ValueError):
         pl.screen_stream(key)
     pl._SCREEN_CHOICE.clear()
+
+
+def test_balanced_chunk_keeps_the_launch_count_and_evens_the_sizes():
+    """pseudolabels.balanced_chunk: the refinement tiers' rows per launch (rows are chunk-independent: tests/test_gpu_exact.py)."""
+    from grip_amd.pseudolabels import balanced_chunk
+    for n, chunk in ((1024, 880), (2445, 880), (880, 880), (881, 880), (2, 880), (1, 1), (0, 880), (50000, 1320), (7, 3)):
+        c = balanced_chunk(n, chunk)
+        assert 1 <= c <= max(chunk, 1)
+        launches = -(-n // chunk) if n else 0
+        assert (-(-n // c) if n else 0) == launches, (n, chunk, c)                # never more launches than the plain chunking
+        if n:
+            sizes = [min(c, n - s) for s in range(0, n, c)]
+            assert max(sizes) - min(sizes) <= launches, (n, chunk, sizes)          # ... and no short tail
+    assert balanced_chunk(1024, 880) == 512 and balanced_chunk(2445, 880) == 815
